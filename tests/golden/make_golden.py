@@ -1,0 +1,293 @@
+"""Generates tests/golden/*.npz.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+What it does: imports the reference's own, unmodified `models/GDN.py`,
+`models/graph_layer.py`, `test.py`, `train.py` and `evaluate.py` from
+/root/reference BY PATH, with `torch_geometric` (absent from the image, pinned 1.5.0
+in the reference's install.sh) bound to oracle/pyg_restatement.py, runs them on
+seeded inputs on the CPU and stores inputs + outputs.  Nothing from the reference's
+source text is stored — only tensors (weights, inputs, outputs) and, for config 1, a
+12-row numeric slice of the reference's demo data file data/msl/test.csv.
+
+    python tests/golden/make_golden.py
+
+PARITY NOTE: the fixtures are "reference model code + restated PyG 1.5.0", see the
+header of oracle/pyg_restatement.py (parity unpinned at the PyG boundary).  The
+scoring fixtures (score_*.npz) come from the reference's evaluate.py + the real
+numpy/scipy and are fully pinned.
+"""
+import importlib
+import importlib.util
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+sys.path.insert(0, ROOT)
+from oracle import pyg_restatement  # noqa: E402
+
+pyg_restatement.install_as_torch_geometric()
+sys.path.insert(0, REF)
+
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+
+ref_gdn = importlib.import_module("models.GDN")            # /root/reference/models/GDN.py
+ref_env = importlib.import_module("util.env")
+ref_env.set_device("cpu")
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+ref_test = _load_by_path("test", os.path.join(REF, "test.py"))      # train.py does `from test import *`
+ref_train = _load_by_path("ref_train", os.path.join(REF, "train.py"))
+ref_eval = _load_by_path("ref_evaluate", os.path.join(REF, "evaluate.py"))
+
+
+class FixedMaskDropout(torch.nn.Module):
+    """Stands in for `model.dp` (nn.Dropout(0.2), models/GDN.py:114) so the train-mode
+    fixture does not depend on an RNG stream: multiplies by pre-drawn masks in order."""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.calls = list(masks), 0
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        m = self.masks[self.calls]
+        self.calls += 1
+        return x * m
+
+
+def fc_edge_index(n):
+    """Fully connected prior graph without self loops, the shape main.py:58-59 builds."""
+    src, dst = [], []
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                src.append(j)
+                dst.append(i)
+    return torch.tensor([src, dst], dtype=torch.long)
+
+
+def build_model(seed, n, w, k, d, out_layers, inter, emb_override=None):
+    torch.manual_seed(seed)
+    model = ref_gdn.GDN([fc_edge_index(n)], n, dim=d, out_layer_inter_dim=inter, input_dim=w,
+                        out_layer_num=out_layers, topk=k)
+    g = torch.Generator().manual_seed(seed + 1000)
+
+    def u(shape, lo, hi):
+        return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+    with torch.no_grad():
+        # perturb everything the reference zero-/identity-initialises so no term is hidden
+        gnn = model.gnn_layers[0].gnn
+        gnn.att_em_i.copy_(u(gnn.att_em_i.shape, -0.1, 0.1))
+        gnn.att_em_j.copy_(u(gnn.att_em_j.shape, -0.1, 0.1))
+        gnn.bias.copy_(u(gnn.bias.shape, -0.1, 0.1))
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_(u(mod.weight.shape, 0.5, 1.5))
+                mod.bias.copy_(u(mod.bias.shape, -0.2, 0.2))
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(u(mod.running_var.shape, 0.5, 1.5))
+        if emb_override is not None:
+            model.embedding.weight.copy_(emb_override)
+    return model
+
+
+def cosine_gap(model, k):
+    w = model.embedding.weight.detach()
+    c = (w @ w.T) / (w.norm(dim=-1).view(-1, 1) @ w.norm(dim=-1).view(1, -1))
+    s = torch.sort(c, dim=-1, descending=True)[0]
+    if k >= s.shape[1]:
+        return float("inf")
+    return float((s[:, k - 1] - s[:, k]).min())
+
+
+def state_arrays(sd, prefix):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def run_case(name, *, seed, b, n, w, k, d=64, out_layers=1, inter=256, x=None, y=None,
+             emb_override=None, note="", min_gap=5e-5):
+    model = build_model(seed, n, w, k, d, out_layers, inter, emb_override)
+    # end-to-end top-k parity needs a k/(k+1) cosine gap no rounding difference can bridge:
+    # walk the seed until the embedding table the reference initialises has one
+    while emb_override is None and cosine_gap(model, k) < min_gap:
+        seed += 100
+        model = build_model(seed, n, w, k, d, out_layers, inter, emb_override)
+    g = torch.Generator().manual_seed(seed + 2000)
+    if x is None:
+        x = torch.rand((b, n, w), generator=g)
+        y = torch.rand((b, n), generator=g)
+    fake_edge_arg = torch.zeros((b, 2, 4))          # 2nd forward arg is ignored (GDN.py:122)
+    out = {"meta_bnwkd": np.array([b, n, w, k, d, out_layers, inter], dtype=np.int64),
+           "x": x.numpy().copy(), "y": y.numpy().copy(),
+           "cos_gap": np.array(cosine_gap(model, k)), "seed": np.array(seed)}
+    out.update(state_arrays(model.state_dict(), "p/"))
+
+    # ---- eval forward (test.py:39-47 usage) + intermediates
+    model.eval()
+    captured = {}
+    hook = model.gnn_layers[0].gnn.register_forward_hook(
+        lambda m, i, o: captured.__setitem__("agg", o[0].detach().clone()))
+    with torch.no_grad():
+        pred = model(x, fake_edge_arg)
+    hook.remove()
+    layer = model.gnn_layers[0]
+    out["eval_out"] = pred.numpy().copy()
+    out["learned_graph"] = model.learned_graph.numpy().copy()
+    out["edge_index_1"] = layer.edge_index_1.numpy().copy()
+    out["att_weight_1"] = layer.att_weight_1.numpy().copy()
+    out["agg"] = captured["agg"].numpy().copy()
+
+    # ---- one train-mode step (train.py:68-72 usage): loss + grads + BN stat updates
+    mask = (torch.rand((b, n, d), generator=g) >= 0.2).float() / 0.8
+    model.dp = FixedMaskDropout([mask])
+    model.train()
+    model.zero_grad()
+    pred_t = model(x, fake_edge_arg)
+    loss = ref_train.loss_func(pred_t, y)
+    loss.backward()
+    out["dropout_mask"] = mask.numpy().copy()
+    out["train_out"] = pred_t.detach().numpy().copy()
+    out["train_loss"] = np.array(loss.item())
+    for pname, prm in model.named_parameters():
+        out["g/" + pname] = prm.grad.detach().numpy().copy()
+    out.update(state_arrays(model.state_dict(), "p_after_train_fwd/"))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    deg = np.bincount(out["edge_index_1"][1][: out["edge_index_1"].shape[1] // 1], minlength=b * n)
+    print(f"{name}: out {out['eval_out'].shape} loss {loss.item():.6f} cos_gap {out['cos_gap']:.3e} "
+          f"deg[min,max]=({deg.min()},{deg.max()}) {note}")
+    return model
+
+
+def msl_slice(w, b):
+    """Config 1 input: the first w+b rows of the reference's demo test series."""
+    import pandas as pd
+    df = pd.read_csv(os.path.join(REF, "data/msl/test.csv"), sep=",", index_col=0)
+    cols = [c.strip() for c in open(os.path.join(REF, "data/msl/list.txt")).read().split("\n") if c.strip()]
+    raw = torch.tensor(df[cols].values[: w + b].T, dtype=torch.float64)   # [N, T] (TimeDataset.py:42)
+    xs = torch.stack([raw[:, t - w:t] for t in range(w, w + b)]).float()   # TimeDataset.py:46-57
+    ys = torch.stack([raw[:, t] for t in range(w, w + b)]).float()
+    return xs, ys, raw.numpy()
+
+
+def degree_k_plus_1_embedding(n, d, k):
+    """Search a seed whose embedding table (a few rows are scaled copies of one another, so their
+    mutual cosines are 1 up to rounding) makes the REFERENCE pick a top-k that omits the row itself
+    for at least one row -> in-degree K+1 after models/graph_layer.py:61-63."""
+    for seed in range(1000):
+        g = torch.Generator().manual_seed(seed)
+        emb = torch.randn((n, d), generator=g)
+        base = emb[0].clone()
+        for r in range(1, k + 3):
+            emb[r] = base * float(torch.rand((), generator=g) * 3 + 0.25)
+        c = (emb @ emb.T) / (emb.norm(dim=-1).view(-1, 1) @ emb.norm(dim=-1).view(1, -1))
+        top = torch.topk(c, k, dim=-1)[1]
+        missing = [i for i in range(n) if i not in top[i].tolist()]
+        if missing:
+            return emb, seed, missing
+    raise RuntimeError("no seed found")
+
+
+def eval_loop_case():
+    """test.py:21-79 driven with a list of batches."""
+    n, w, k, d, bsz, nb = 27, 5, 5, 64, 4, 3
+    model = build_model(11, n, w, k, d, 1, 256)
+    g = torch.Generator().manual_seed(77)
+    xs = torch.rand((bsz * nb, n, w), generator=g).double()
+    ys = torch.rand((bsz * nb, n), generator=g).double()
+    labels = (torch.rand((bsz * nb,), generator=g) > 0.7).double()
+    ei = fc_edge_index(n)
+    batches = [(xs[i * bsz:(i + 1) * bsz], ys[i * bsz:(i + 1) * bsz], labels[i * bsz:(i + 1) * bsz],
+                ei.unsqueeze(0).repeat(bsz, 1, 1)) for i in range(nb)]
+    avg_loss, (pred, gt, lab) = ref_test.test(model, batches)
+    out = {"meta_bnwkd": np.array([bsz, n, w, k, d, 1, 256], dtype=np.int64),
+           "x": xs.float().numpy(), "y": ys.float().numpy(), "labels": labels.float().numpy(),
+           "avg_loss": np.array(avg_loss), "pred": np.array(pred, dtype=np.float32),
+           "gt": np.array(gt, dtype=np.float32), "lab": np.array(lab, dtype=np.float32)}
+    out.update(state_arrays(model.state_dict(), "p/"))
+    # scoring of exactly these predictions by the reference (evaluate.py:6-36)
+    scores, normals = ref_eval.get_full_err_scores([pred, gt, lab], [pred, gt, lab])
+    out["scores"] = np.asarray(scores)
+    np.savez_compressed(os.path.join(HERE, "eval_loop_msl_shape.npz"), **out)
+    print(f"eval_loop: avg_loss {avg_loss:.6f} pred {out['pred'].shape} scores {out['scores'].shape}")
+
+
+def train_loop_case():
+    """train.py:27-112 for 1 epoch × 2 batches (Adam lr 1e-3), no val loader."""
+    n, w, k, d, bsz, nb = 16, 6, 4, 32, 5, 2
+    model = build_model(21, n, w, k, d, 1, 256)
+    g = torch.Generator().manual_seed(99)
+    xs = torch.rand((bsz * nb, n, w), generator=g)
+    ys = torch.rand((bsz * nb, n), generator=g)
+    masks = [(torch.rand((bsz, n, d), generator=g) >= 0.2).float() / 0.8 for _ in range(nb)]
+    model.dp = FixedMaskDropout(masks)
+    ei = fc_edge_index(n)
+    batches = [(xs[i * bsz:(i + 1) * bsz], ys[i * bsz:(i + 1) * bsz], torch.zeros(bsz),
+                ei.unsqueeze(0).repeat(bsz, 1, 1)) for i in range(nb)]
+    out = {"meta_bnwkd": np.array([bsz, n, w, k, d, 1, 256], dtype=np.int64),
+           "x": xs.numpy(), "y": ys.numpy(), "masks": torch.stack(masks).numpy()}
+    out.update(state_arrays(model.state_dict(), "p/"))
+    save_path = "/tmp/_gdn_golden_train.pt"
+    losses = ref_train.train(model, save_path, config={"seed": 0, "decay": 0.0, "epoch": 1},
+                             train_dataloader=batches, val_dataloader=None)
+    out["losses"] = np.array(losses)
+    out.update(state_arrays(model.state_dict(), "p_final/"))
+    np.savez_compressed(os.path.join(HERE, "train_loop_2step.npz"), **out)
+    print(f"train_loop: losses {losses}")
+
+
+def score_cases():
+    """evaluate.py:6-68 on random [T,N] predictions, even and odd T."""
+    for t, n, seed in ((64, 5, 3), (65, 7, 4), (1000, 27, 5)):
+        g = torch.Generator().manual_seed(seed)
+        pred = torch.rand((t, n), generator=g)
+        gt = (pred + 0.1 * torch.randn((t, n), generator=g)).float()
+        gt[t // 2: t // 2 + 3] += 1.5                      # an "attack" burst
+        lab = torch.zeros((t, n))
+        res = [pred.tolist(), gt.tolist(), lab.tolist()]   # the list form test.py:73-75 returns
+        scores, _ = ref_eval.get_full_err_scores(res, res)
+        med_iqr = np.array([ref_eval.get_err_median_and_iqr(pred[:, i].tolist(), gt[:, i].tolist())
+                            for i in range(n)])
+        np.savez_compressed(os.path.join(HERE, f"score_T{t}_N{n}.npz"), pred=pred.numpy(), gt=gt.numpy(),
+                            scores=np.asarray(scores), med_iqr=med_iqr)
+        print(f"score T={t} N={n}: scores {np.asarray(scores).shape}")
+
+
+def main():
+    torch.set_num_threads(4)
+    xs, ys, raw = msl_slice(5, 8)
+    run_case("msl_demo_w5_k5", seed=5, b=8, n=27, w=5, k=5, x=xs, y=ys,
+             note="(input = first 13 rows of data/msl/test.csv)")
+    np.savez_compressed(os.path.join(HERE, "msl_raw_slice.npz"), raw=raw)
+    run_case("fc64_w15_k64", seed=1, b=2, n=64, w=15, k=64)
+    run_case("swat127_w15_k30", seed=2, b=2, n=127, w=15, k=30)
+    run_case("mlp2_n20_w8_k6", seed=3, b=3, n=20, w=8, k=6, d=32, out_layers=2, inter=48)
+    run_case("mlp3_n12_w4_k3", seed=4, b=5, n=12, w=4, k=3, d=16, out_layers=3, inter=24)
+    emb, eseed, missing = degree_k_plus_1_embedding(10, 64, 3)
+    run_case("dupemb_n10_k3", seed=6, b=3, n=10, w=7, k=3, emb_override=emb,
+             note=f"(emb seed {eseed}; rows without self in own top-k: {missing})")
+    run_case("wadi_stress_small_n40_w30_k16_d128", seed=7, b=2, n=40, w=30, k=16, d=128)
+    eval_loop_case()
+    train_loop_case()
+    score_cases()
+
+
+if __name__ == "__main__":
+    main()

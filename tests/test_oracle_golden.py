@@ -1,0 +1,96 @@
+"""CPU suite, part 1: the oracle (oracle/*.py) against the golden vectors captured from the
+reference's own model / evaluate files (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODEL_CASES, SCORE_CASES, load_golden, meta
+from oracle import gdn_oracle, score_oracle
+
+FP32_TOL = 1e-5   # oracle vs reference run: same ops, same library -> only summation-order noise
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_eval_forward_matches_reference(case):
+    data, p = load_golden(case)
+    m = meta(data)
+    x = torch.from_numpy(data["x"])
+    r = gdn_oracle.forward(p, x, m["k"], m["out_layer_num"])
+    assert torch.equal(r["learned_graph"], torch.from_numpy(data["learned_graph"]))
+    assert torch.equal(r["edge_index_1"], torch.from_numpy(data["edge_index_1"]))
+    np.testing.assert_allclose(r["att_weight_1"].numpy(), data["att_weight_1"], atol=FP32_TOL, rtol=0)
+    np.testing.assert_allclose(r["agg"].numpy(), data["agg"], atol=FP32_TOL, rtol=0)
+    np.testing.assert_allclose(r["out"].numpy(), data["eval_out"], atol=FP32_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_separable_spec_matches_op_faithful(case):
+    data, p = load_golden(case)
+    m = meta(data)
+    x = torch.from_numpy(data["x"])
+    g = torch.from_numpy(data["learned_graph"])
+    r = gdn_oracle.forward_separable(p, x, g, m["out_layer_num"])
+    np.testing.assert_allclose(r["agg"].numpy(), data["agg"], atol=FP32_TOL, rtol=0)
+    np.testing.assert_allclose(r["out"].numpy(), data["eval_out"], atol=FP32_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_train_step_loss_grads_and_bn_stats(case):
+    data, p = load_golden(case)
+    m = meta(data)
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+            for k, v in p.items()}
+    x = torch.from_numpy(data["x"])
+    y = torch.from_numpy(data["y"])
+    r = gdn_oracle.forward(leaf, x, m["k"], m["out_layer_num"], training=True,
+                           dropout_mask=torch.from_numpy(data["dropout_mask"]))
+    loss = torch.nn.functional.mse_loss(r["out"], y, reduction="mean")   # train.py:20-23
+    loss.backward()
+    np.testing.assert_allclose(r["out"].detach().numpy(), data["train_out"], atol=FP32_TOL, rtol=0)
+    np.testing.assert_allclose(loss.item(), float(data["train_loss"]), atol=FP32_TOL, rtol=0)
+    for key in data:
+        if key.startswith("g/"):
+            got = leaf[key[2:]].grad
+            assert got is not None, key
+            np.testing.assert_allclose(got.numpy(), data[key], atol=2e-5, rtol=1e-4, err_msg=key)
+    for key, val in r["new_stats"].items():
+        np.testing.assert_allclose(val.numpy(), data["p_after_train_fwd/" + key], atol=FP32_TOL, rtol=0,
+                                   err_msg=key)
+
+
+def test_degree_k_plus_one_case_is_really_in_the_fixture():
+    data, _ = load_golden("dupemb_n10_k3")
+    m = meta(data)
+    ei = data["edge_index_1"]
+    deg = np.bincount(ei[1], minlength=m["b"] * m["n"])
+    assert deg.min() == m["k"] and deg.max() == m["k"] + 1
+
+
+@pytest.mark.parametrize("case", SCORE_CASES)
+def test_scoring_matches_reference_evaluate(case):
+    data, _ = load_golden(case)
+    s = score_oracle.full_err_scores(data["pred"], data["gt"])
+    np.testing.assert_allclose(s, data["scores"], atol=1e-12, rtol=1e-12)
+    for i in range(data["pred"].shape[1]):
+        # the reference feeds python-float lists of the fp32 values: identical numbers in float64
+        med, rng = score_oracle.err_median_and_iqr(data["pred"][:, i], data["gt"][:, i])
+        np.testing.assert_allclose([med, rng], data["med_iqr"][i], atol=0, rtol=1e-15)
+    a = score_oracle.anomaly_score(s, topk=1)
+    np.testing.assert_array_equal(a, s.max(axis=0))
+
+
+def test_eval_loop_fixture_consistent_with_oracle():
+    data, p = load_golden("eval_loop_msl_shape")
+    m = meta(data)
+    x = torch.from_numpy(data["x"])
+    y = torch.from_numpy(data["y"])
+    preds, losses = [], []
+    for s in range(0, x.shape[0], m["b"]):                       # test.py:43-65
+        out = gdn_oracle.forward(p, x[s:s + m["b"]], m["k"])["out"]
+        preds.append(out)
+        losses.append(torch.nn.functional.mse_loss(out, y[s:s + m["b"]]).item())
+    pred = torch.cat(preds)
+    np.testing.assert_allclose(pred.numpy(), data["pred"], atol=FP32_TOL, rtol=0)
+    np.testing.assert_allclose(sum(losses) / len(losses), float(data["avg_loss"]), atol=1e-6)
+    s = score_oracle.full_err_scores(data["pred"].astype(np.float64), data["gt"].astype(np.float64))
+    np.testing.assert_allclose(s, data["scores"], atol=1e-12, rtol=1e-12)
