@@ -1,0 +1,66 @@
+"""ctypes binding of libgdn_hip.so (C ABI declared in include/gdn_hip.h).
+
+There is NO CPU fallback: if the shared library has not been built, or a tensor is not on
+a HIP device, every op raises.  Build with `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgdn_hip.so")
+ABI_VERSION = 1
+
+_c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (restype is always int); mirrors include/gdn_hip.h one to one
+SIGNATURES = {
+    "gdn_abi_version": [],
+    "gdn_nbr_pitch": [_c_int],
+    "gdn_topk_graph": [_p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p],
+    "gdn_graph_from_topk": [_p, _c_int, _c_int, _p, _p, _p],
+    "gdn_node_terms": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p],
+    "gdn_bn_fold": [_p, _p, _p, _p, _c_float, _c_int, _p, _p],
+    "gdn_project_fwd": [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p],
+    "gdn_attn_aggregate_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
+    "gdn_head_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],
+    "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],
+    # TODO(next commit): gdn_attn_aggregate_bwd, gdn_project_bwd, gdn_score_quantiles, gdn_score_smooth_max
+}
+
+ERRORS = {-1: "GDN_ERR_ARG (null pointer or non-positive dimension)",
+          -2: "GDN_ERR_LAUNCH (HIP launch failed)",
+          -3: "GDN_ERR_UNSUPPORTED (shape outside the supported set, see include/gdn_hip.h)"}
+
+_lib = None
+
+
+class GdnHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it is missing or from another ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdnHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built and gdn_amd has no CPU "
+            "fallback. Run `python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    if lib.gdn_abi_version() != ABI_VERSION:
+        raise GdnHipError(f"ABI mismatch: library {lib.gdn_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise GdnHipError(f"{name} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 GDN kernels.  wave = 64 lanes, DPP "row" = 16 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gdn_hip.h"
+
+#define GDN_NEG_SLOPE 0.2f      // LeakyReLU slope, reference models/graph_layer.py:13
+#define GDN_SOFTMAX_EPS 1e-16f  // torch_geometric.utils.softmax 1.5.0 denominator epsilon
+#define GDN_MAX_W 64
+#define GDN_A_PITCH 64          // a_i / a_j are stored zero padded to 64 floats
+
+static inline int gdn_launch_status() {
+  return hipGetLastError() == hipSuccess ? GDN_OK : GDN_ERR_LAUNCH;
+}
+
+static inline int gdn_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// ---- DPP within a 16-lane row ------------------------------------------------------
+// dpp_ctrl encodings (gfx9): quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_mirror 0x140,
+// row_half_mirror 0x141.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+#define GDN_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define GDN_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define GDN_DPP_HALF_MIRROR 0x141  // lane i <-> 7-i inside each 8
+#define GDN_DPP_MIRROR 0x140       // lane i <-> 15-i inside each 16
+#define GDN_DPP_ROR1 0x121         // rotate the 16-lane row by one lane
+
+// All 16 lanes of a row end with the row's sum / max.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<GDN_DPP_XOR1>(v);
+  v += dpp_f<GDN_DPP_XOR2>(v);
+  v += dpp_f<GDN_DPP_HALF_MIRROR>(v);
+  v += dpp_f<GDN_DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<GDN_DPP_XOR1>(v));
+  v = fmaxf(v, dpp_f<GDN_DPP_XOR2>(v));
+  v = fmaxf(v, dpp_f<GDN_DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<GDN_DPP_MIRROR>(v));
+  return v;
+}
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * GDN_NEG_SLOPE; }
+
+// 64-lane wave sum through DPP + readlane (used by the small reduction kernels).
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}

@@ -1,0 +1,169 @@
+// Sensor-graph construction and per-forward constants (run once per weight update;
+// microseconds of work, so the kernels favour exactness and determinism over speed).
+#include "gdn_common.hpp"
+
+extern "C" int gdn_abi_version(void) { return GDN_ABI_VERSION; }
+extern "C" int gdn_nbr_pitch(int k) { return ((k + 1) + 15) & ~15; }
+
+namespace {
+
+// "a ranks before b" in the descending order torch.topk uses: larger first, NaN largest;
+// ties go to the lower index (torch leaves tie order unspecified; this is our rule).
+__device__ __forceinline__ bool ranks_before(float a, int ia, float b, int ib) {
+  const bool an = a != a, bn = b != b;
+  if (an || bn) {
+    if (an && bn) return ia < ib;
+    return an;
+  }
+  if (a > b) return true;
+  if (a < b) return false;
+  return ia < ib;
+}
+
+// Neighbour list of target i from the ranks of all sensors (rank < k = member of top-k):
+// entries != i keep their rank order, then i itself (models/graph_layer.py:61-63), padding = i.
+__device__ __forceinline__ void emit_list(const int* __restrict__ rank_of, int i, int n, int k,
+                                          int pitch, uint16_t* __restrict__ nbr_row,
+                                          int32_t* __restrict__ deg_i) {
+  const int self_rank = rank_of[i];
+  const int nonself = k - (self_rank < k ? 1 : 0);
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int r = rank_of[j];
+    if (r < k && j != i) nbr_row[r - (self_rank < r ? 1 : 0)] = (uint16_t)j;
+  }
+  for (int p = nonself + threadIdx.x; p < pitch; p += blockDim.x) nbr_row[p] = (uint16_t)i;
+  if (threadIdx.x == 0) *deg_i = nonself + 1;
+}
+
+// One workgroup per target sensor i: reference models/GDN.py:148-159 (cosine row, top-k),
+// then the list form of :161-163.
+__global__ __launch_bounds__(256) void gdn_graph_kernel(
+    const float* __restrict__ emb, int n, int d, int k, int pitch, int64_t* __restrict__ topk_idx,
+    uint16_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ cos_out) {
+  extern __shared__ float smem_graph[];
+  float* cosrow = smem_graph;                            // [n]
+  int* rank_of = reinterpret_cast<int*>(smem_graph + n);  // [n]
+  const int i = blockIdx.x;
+  const float* ei = emb + (size_t)i * d;
+
+  float ni2 = 0.f;
+  for (int t = 0; t < d; ++t) ni2 = fmaf(ei[t], ei[t], ni2);
+  const float ni = sqrtf(ni2);
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const float* ej = emb + (size_t)j * d;
+    float dot = 0.f, nj2 = 0.f;
+    for (int t = 0; t < d; ++t) {
+      dot = fmaf(ei[t], ej[t], dot);
+      nj2 = fmaf(ej[t], ej[t], nj2);
+    }
+    const float c = dot / (ni * sqrtf(nj2));  // GDN.py:152 has no epsilon: zero rows give NaN
+    cosrow[j] = c;
+    if (cos_out) cos_out[(size_t)i * n + j] = c;
+  }
+  __syncthreads();
+  // rank by counting: deterministic, n^2 compares per row, no sorting network.
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const float cj = cosrow[j];
+    int rank = 0;
+    for (int l = 0; l < n; ++l) rank += ranks_before(cosrow[l], l, cj, j) ? 1 : 0;
+    rank_of[j] = rank;
+    if (rank < k) topk_idx[(size_t)i * k + rank] = j;
+  }
+  __syncthreads();
+  emit_list(rank_of, i, n, k, pitch, nbr + (size_t)i * pitch, deg + i);
+}
+
+// Same list build from a given [n,k] top-k table.
+__global__ __launch_bounds__(256) void gdn_graph_from_topk_kernel(
+    const int64_t* __restrict__ topk_idx, int n, int k, int pitch, uint16_t* __restrict__ nbr,
+    int32_t* __restrict__ deg) {
+  extern __shared__ float smem_graph[];
+  int* rank_of = reinterpret_cast<int*>(smem_graph);  // [n]
+  const int i = blockIdx.x;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) rank_of[j] = k;  // "not in top-k"
+  __syncthreads();
+  for (int r = threadIdx.x; r < k; r += blockDim.x) {
+    const int64_t j = topk_idx[(size_t)i * k + r];
+    if (j >= 0 && j < n) rank_of[j] = r;
+  }
+  __syncthreads();
+  emit_list(rank_of, i, n, k, pitch, nbr + (size_t)i * pitch, deg + i);
+}
+
+// a_i = lin^T att_i, a_j = lin^T att_j (zero padded to 64), c_i[s] = v_s.att_em_i, c_j[s].
+__global__ __launch_bounds__(256) void gdn_node_terms_kernel(
+    const float* __restrict__ lin_w, const float* __restrict__ att_i, const float* __restrict__ att_j,
+    const float* __restrict__ att_em_i, const float* __restrict__ att_em_j,
+    const float* __restrict__ emb, int n, int d, int w, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 2 * GDN_A_PITCH) {
+    const int col = t % GDN_A_PITCH;
+    const float* att = t < GDN_A_PITCH ? att_i : att_j;
+    float acc = 0.f;
+    if (col < w)
+      for (int r = 0; r < d; ++r) acc = fmaf(lin_w[(size_t)r * w + col], att[r], acc);
+    out[t] = acc;
+  } else if (t < 2 * GDN_A_PITCH + 2 * n) {
+    const int u = t - 2 * GDN_A_PITCH;
+    const int s = u % n;
+    const float* att = u < n ? att_em_i : att_em_j;
+    float acc = 0.f;
+    for (int r = 0; r < d; ++r) acc = fmaf(emb[(size_t)s * d + r], att[r], acc);
+    out[t] = acc;
+  }
+}
+
+__global__ void gdn_bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                                   const float* __restrict__ mean, const float* __restrict__ var,
+                                   float eps, int c, float* __restrict__ affine) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < c) {
+    const float scale = weight[t] / sqrtf(var[t] + eps);
+    affine[t] = scale;
+    affine[c + t] = bias[t] - mean[t] * scale;
+  }
+}
+
+}  // namespace
+
+extern "C" int gdn_topk_graph(const float* emb, int n, int d, int k, int64_t* topk_idx, uint16_t* nbr,
+                              int32_t* deg, float* cos_out, void* stream) {
+  if (!emb || !topk_idx || !nbr || !deg || n <= 0 || d <= 0 || k <= 0) return GDN_ERR_ARG;
+  if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
+  const int pitch = gdn_nbr_pitch(k);
+  hipLaunchKernelGGL(gdn_graph_kernel, dim3(n), dim3(256), 2 * n * sizeof(float), (hipStream_t)stream,
+                     emb, n, d, k, pitch, topk_idx, nbr, deg, cos_out);
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_graph_from_topk(const int64_t* topk_idx, int n, int k, uint16_t* nbr, int32_t* deg,
+                                   void* stream) {
+  if (!topk_idx || !nbr || !deg || n <= 0 || k <= 0) return GDN_ERR_ARG;
+  if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
+  const int pitch = gdn_nbr_pitch(k);
+  hipLaunchKernelGGL(gdn_graph_from_topk_kernel, dim3(n), dim3(256), n * sizeof(int),
+                     (hipStream_t)stream, topk_idx, n, k, pitch, nbr, deg);
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_node_terms(const float* lin_w, const float* att_i, const float* att_j,
+                              const float* att_em_i, const float* att_em_j, const float* emb, int n,
+                              int d, int w, float* node_terms, void* stream) {
+  if (!lin_w || !att_i || !att_j || !att_em_i || !att_em_j || !emb || !node_terms || n <= 0 ||
+      d <= 0 || w <= 0)
+    return GDN_ERR_ARG;
+  if (w > GDN_MAX_W) return GDN_ERR_UNSUPPORTED;
+  const int total = 2 * GDN_A_PITCH + 2 * n;
+  hipLaunchKernelGGL(gdn_node_terms_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, lin_w, att_i, att_j, att_em_i, att_em_j, emb, n, d, w,
+                     node_terms);
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_bn_fold(const float* weight, const float* bias, const float* running_mean,
+                           const float* running_var, float eps, int c, float* affine, void* stream) {
+  if (!weight || !bias || !running_mean || !running_var || !affine || c <= 0) return GDN_ERR_ARG;
+  hipLaunchKernelGGL(gdn_bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     weight, bias, running_mean, running_var, eps, c, affine);
+  return gdn_launch_status();
+}

@@ -1,0 +1,291 @@
+"""Host-side mirror of the reference's model interface (models/GDN.py, models/graph_layer.py).
+
+Same class names, constructor arguments, `forward(data, org_edge_index) -> [batch, node_num]`
+signature, side attributes (`learned_graph`, `att_weight_1`, `edge_index_1`) and
+`state_dict()` keys / shapes, so a reference checkpoint loads here and vice versa, and
+`train.py` / `test.py`-style loops run unchanged.
+
+The torch modules below are PARAMETER CONTAINERS (they give the reference's state_dict
+layout and initialisation stream); the arithmetic of the hot path runs in hand-written HIP
+kernels reached through gdn_amd.ops -> libgdn_hip.so.  There is no CPU path: calling
+forward on CPU tensors raises.
+
+  eval, out_layer_num == 1 : one fused launch  x[B,N,W] -> out[B,N]       (ops.forward_fused)
+  eval, otherwise          : project -> attention/aggregate -> head kernels, OutLayer MLP
+                             through torch (plain library GEMMs)
+  train                    : project + attention/aggregate forward AND backward are HIP kernels
+                             (autograd.Function below); BatchNorm batch statistics, dropout
+                             and the output MLP use torch ops so `loss.backward()` reaches
+                             every parameter exactly as in the reference.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _glorot(t: torch.Tensor) -> None:
+    """torch_geometric.nn.inits.glorot (1.5.0): U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))."""
+    bound = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    t.data.uniform_(-bound, bound)
+
+
+class GraphLayer(nn.Module):
+    """Parameters of the reference GraphLayer (models/graph_layer.py:12-49), heads = 1,
+    concat = False as hard-wired by GNNLayer (models/GDN.py:65)."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=False, negative_slope=0.2,
+                 dropout=0, bias=True, inter_dim=-1, **kwargs):
+        super().__init__()
+        if heads != 1 or concat or dropout != 0 or not bias or negative_slope != 0.2:
+            raise NotImplementedError("the GDN hot path uses heads=1, concat=False, dropout=0, "
+                                      "negative_slope=0.2, bias=True (models/GDN.py:65)")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_i = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_j = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_em_i = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_em_j = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # same order and RNG draws as models/graph_layer.py:41-49
+        _glorot(self.lin.weight)
+        _glorot(self.att_i)
+        _glorot(self.att_j)
+        self.att_em_i.data.fill_(0)
+        self.att_em_j.data.fill_(0)
+        self.bias.data.fill_(0)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, heads={self.heads})"
+
+
+class _GraphAttentionFn(torch.autograd.Function):
+    """project + attention/aggregate with hand-written forward and backward kernels
+    (reference models/graph_layer.py:53-117 and the autograd graph behind train.py:72)."""
+
+    @staticmethod
+    def forward(ctx, x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, bias, graph, batch):
+        terms = ops.node_terms(lin_w, att_i, att_j, att_em_i, att_em_j, emb)
+        xlin, s_i, s_j = ops.project_fwd(x, lin_w, terms)
+        z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, graph, bias, batch, want_alpha=True)
+        ctx.save_for_backward(x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, xlin, s_i, s_j, alpha)
+        ctx.graph, ctx.batch = graph, batch
+        ctx.mark_non_differentiable(alpha)
+        return z, alpha
+
+    @staticmethod
+    def backward(ctx, d_z, _d_alpha):
+        x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, xlin, s_i, s_j, alpha = ctx.saved_tensors
+        d_xlin, d_si, d_sj, d_bias = ops.attn_aggregate_bwd(d_z.contiguous(), xlin, alpha, s_i, s_j,
+                                                            ctx.graph, ctx.batch)
+        d_lin_w, d_a, d_c = ops.project_bwd(x, d_xlin, d_si, d_sj, lin_w.shape[0])
+        w = lin_w.shape[1]
+        # chain rule through the folded constants  a = lin^T att,  c = emb att_em  (tiny [d,w] / [n,d])
+        ai, aj = att_i.reshape(-1), att_j.reshape(-1)
+        d_lin_w = d_lin_w + torch.outer(ai, d_a[0, :w]) + torch.outer(aj, d_a[1, :w])
+        d_att_i = (lin_w @ d_a[0, :w]).view_as(att_i)
+        d_att_j = (lin_w @ d_a[1, :w]).view_as(att_j)
+        d_att_em_i = (emb.t() @ d_c[0]).view_as(att_em_i)
+        d_att_em_j = (emb.t() @ d_c[1]).view_as(att_em_j)
+        d_emb = torch.outer(d_c[0], att_em_i.reshape(-1)) + torch.outer(d_c[1], att_em_j.reshape(-1))
+        return None, d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb, d_bias, None, None
+
+
+class GNNLayer(nn.Module):
+    """models/GDN.py:60-79.  `att_weight_1` / `edge_index_1` are materialised lazily in the
+    reference's edge-list format from the dense per-target attention table."""
+
+    def __init__(self, in_channel, out_channel, inter_dim=0, heads=1, node_num=100):
+        super().__init__()
+        self.gnn = GraphLayer(in_channel, out_channel, inter_dim=inter_dim, heads=heads, concat=False)
+        self.bn = nn.BatchNorm1d(out_channel)
+        self.relu = nn.ReLU()
+        self.leaky_relu = nn.LeakyReLU()
+        self._dense = None      # (alpha[B*n, pitch], graph, batch) of the last forward, or a thunk
+
+    def _set_dense(self, value):
+        self._dense = value
+
+    def _materialise(self):
+        if self._dense is None:
+            raise AttributeError("att_weight_1 / edge_index_1 exist only after a forward pass")
+        if callable(self._dense):
+            self._dense = self._dense()
+        return self._dense
+
+    @property
+    def edge_index_1(self) -> torch.Tensor:
+        """[2, E'] int64: non-self edges window-major / target-major / rank order, then one
+        self-loop per node (models/graph_layer.py:61-63 applied to models/GDN.py:161-165)."""
+        _, graph, batch = self._materialise()
+        n, k = graph.topk.shape
+        dev = graph.topk.device
+        src = graph.topk.reshape(-1)
+        tgt = torch.arange(n, device=dev).repeat_interleave(k)
+        keep = src != tgt
+        src, tgt = src[keep], tgt[keep]
+        shift = (torch.arange(batch, device=dev) * n).view(-1, 1)
+        loops = torch.arange(batch * n, device=dev)
+        return torch.stack((torch.cat(((src.view(1, -1) + shift).reshape(-1), loops)),
+                            torch.cat(((tgt.view(1, -1) + shift).reshape(-1), loops))))
+
+    @property
+    def att_weight_1(self) -> torch.Tensor:
+        """[E', 1, 1] attention weights in `edge_index_1` order."""
+        alpha, graph, batch = self._materialise()
+        n = graph.n
+        a = alpha.view(batch, n, graph.pitch)
+        deg = graph.deg.long()
+        slots = torch.arange(graph.pitch, device=alpha.device).view(1, -1)
+        nonself = slots < (deg.view(-1, 1) - 1)                       # [n, pitch]
+        self_w = torch.gather(a, 2, (deg - 1).view(1, n, 1).expand(batch, n, 1)).reshape(-1)
+        return torch.cat((a[:, nonself], self_w)).view(-1, 1, 1)
+
+
+class OutLayer(nn.Module):
+    """models/GDN.py:27-56."""
+
+    def __init__(self, in_num, node_num, layer_num, inter_num=512):
+        super().__init__()
+        modules = []
+        for i in range(layer_num):
+            if i == layer_num - 1:
+                modules.append(nn.Linear(in_num if layer_num == 1 else inter_num, 1))
+            else:
+                modules.append(nn.Linear(in_num if i == 0 else inter_num, inter_num))
+                modules.append(nn.BatchNorm1d(inter_num))
+                modules.append(nn.ReLU())
+        self.mlp = nn.ModuleList(modules)
+
+    def forward(self, x):
+        out = x
+        for mod in self.mlp:
+            if isinstance(mod, nn.BatchNorm1d):
+                out = mod(out.permute(0, 2, 1)).permute(0, 2, 1)
+            else:
+                out = mod(out)
+        return out
+
+
+class _EvalConstants:
+    __slots__ = ("key", "graph", "terms", "bn1", "bn2")
+
+
+class GDN(nn.Module):
+    """Drop-in for the reference `GDN` (models/GDN.py:82-187)."""
+
+    def __init__(self, edge_index_sets, node_num, dim=64, out_layer_inter_dim=256, input_dim=10,
+                 out_layer_num=1, topk=20):
+        super().__init__()
+        if len(edge_index_sets) != 1:
+            # models/GDN.py:176 multiplies a [B,N,dim*sets] tensor by a [N,dim] one: only 1 set works
+            raise NotImplementedError("the reference forward only runs with exactly one edge-index set")
+        self.edge_index_sets = edge_index_sets          # kept for API parity; forward ignores it (GDN.py:122)
+        embed_dim = dim
+        # construction order = the reference's, so a given torch seed yields identical parameters
+        self.embedding = nn.Embedding(node_num, embed_dim)
+        self.bn_outlayer_in = nn.BatchNorm1d(embed_dim)
+        edge_set_num = len(edge_index_sets)
+        self.gnn_layers = nn.ModuleList([
+            GNNLayer(input_dim, dim, inter_dim=dim + embed_dim, heads=1) for _ in range(edge_set_num)])
+        self.node_embedding = None
+        self.topk = topk
+        self.learned_graph = None
+        self.out_layer_num = out_layer_num
+        self.out_layer = OutLayer(dim * edge_set_num, node_num, out_layer_num, inter_num=out_layer_inter_dim)
+        self.cache_edge_index_sets = [None] * edge_set_num
+        self.cache_embed_index = None
+        self.dp = nn.Dropout(0.2)
+        self.injected_graph = None      # optional [N,K] int64 table overriding the learned top-k
+        self._consts = None
+        self.init_params()
+
+    def init_params(self):
+        nn.init.kaiming_uniform_(self.embedding.weight, a=math.sqrt(5))
+
+    # ------------------------------------------------------------------ constants
+    def _param_key(self):
+        ps = [self.embedding.weight, *self.gnn_layers[0].parameters(), *self.bn_outlayer_in.parameters(),
+              *self.gnn_layers[0].bn.buffers(), *self.bn_outlayer_in.buffers()]
+        inj = None if self.injected_graph is None else (self.injected_graph.data_ptr(), self.injected_graph._version)
+        return tuple((p.data_ptr(), p._version) for p in ps) + (self.training, inj)
+
+    def _constants(self) -> _EvalConstants:
+        """Sensor graph + folded per-forward constants; rebuilt only when a parameter changed."""
+        key = self._param_key()
+        c = self._consts
+        if c is not None and c.key == key:
+            return c
+        gnn = self.gnn_layers[0].gnn
+        c = _EvalConstants()
+        c.key = key
+        emb = self.embedding.weight
+        if self.injected_graph is not None:
+            c.graph = ops.graph_from_topk(self.injected_graph.to(emb.device))
+        else:
+            c.graph = ops.topk_graph(emb, self.topk)                       # GDN.py:145-159
+        c.terms = ops.node_terms(gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i, gnn.att_em_j, emb)
+        c.bn1 = c.bn2 = None
+        if not self.training:
+            c.bn1 = ops.bn_fold(self.gnn_layers[0].bn)
+            c.bn2 = ops.bn_fold(self.bn_outlayer_in)
+        self._consts = c
+        return c
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data, org_edge_index=None):
+        x = data.detach()                                                   # GDN.py:124
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        batch, node_num, _ = x.shape
+        layer = self.gnn_layers[0]
+        gnn = layer.gnn
+        c = self._constants()
+        self.learned_graph = c.graph.topk                                   # GDN.py:159
+        emb = self.embedding.weight
+
+        if not self.training:
+            if self.out_layer_num == 1:
+                lin = self.out_layer.mlp[0]
+                out = ops.forward_fused(x, gnn.lin.weight, c.terms, c.graph, gnn.bias, emb, c.bn1, c.bn2,
+                                        lin.weight, lin.bias)
+                layer._set_dense(lambda: self._dense_attention(x, c, batch))
+                return out
+            xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
+            z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True)
+            layer._set_dense((alpha, c.graph, batch))
+            # out_layer_num > 1: the head kernel hands its [BN,d] activation to the OutLayer MLP
+            # (plain library GEMMs through torch); its own Linear(d->1) result is unused here
+            zero_w = torch.zeros((emb.shape[1],), device=x.device)
+            zero_b = torch.zeros((1,), device=x.device)
+            _, h2 = ops.head_fwd(z, emb, c.bn1, c.bn2, zero_w, zero_b, batch, want_h2=True)
+            with torch.no_grad():
+                out = self.out_layer(h2.view(batch, node_num, -1))
+            return out.view(-1, node_num)
+
+        # ---- training: HIP forward/backward for the graph layer, torch for BN statistics etc.
+        z, alpha = _GraphAttentionFn.apply(x, gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i,
+                                           gnn.att_em_j, emb, gnn.bias, c.graph, batch)
+        layer._set_dense((alpha, c.graph, batch))
+        h = layer.relu(layer.bn(z))                                         # GDN.py:77-79
+        h = h.view(batch, node_num, -1)                                     # GDN.py:171-172
+        h = torch.mul(h, emb)                                               # GDN.py:175-176
+        h = F.relu(self.bn_outlayer_in(h.permute(0, 2, 1))).permute(0, 2, 1)   # GDN.py:178-180
+        h = self.dp(h)                                                      # GDN.py:182
+        return self.out_layer(h).view(-1, node_num)                         # GDN.py:183-184
+
+    def _dense_attention(self, x, c, batch):
+        gnn = self.gnn_layers[0].gnn
+        xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
+        _, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True)
+        return alpha, c.graph, batch

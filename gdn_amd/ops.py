@@ -1,0 +1,135 @@
+"""Tensor-level wrappers over the C ABI (include/gdn_hip.h): PyTorch-ROCm tensors in,
+tensors out.  torch is used for device memory and the current HIP stream only; all
+arithmetic happens in libgdn_hip.so.  Every function raises if a tensor is not on a HIP
+device — there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.GdnHipError(f"{name} is on {t.device}: gdn_amd ops need a HIP device (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def nbr_pitch(k: int) -> int:
+    return ((k + 1) + 15) & ~15
+
+
+class SensorGraph:
+    """Neighbour lists shared by every window (reference models/GDN.py:148-165 and
+    models/graph_layer.py:61-63 in list form).  topk: [n,k] int64 = `learned_graph`."""
+
+    def __init__(self, topk, nbr, deg, cos=None):
+        self.topk, self.nbr, self.deg, self.cos = topk, nbr, deg, cos
+        self.n, self.k = topk.shape
+        self.pitch = nbr.shape[1]
+
+
+def topk_graph(emb: torch.Tensor, k: int, want_cos: bool = False) -> SensorGraph:
+    emb = _chk(emb.detach(), name="embedding")            # graph is built on a detached copy (GDN.py:145)
+    n, d = emb.shape
+    dev = emb.device
+    topk = torch.empty((n, k), dtype=torch.int64, device=dev)
+    nbr = torch.empty((n, nbr_pitch(k)), dtype=torch.uint16, device=dev)
+    deg = torch.empty((n,), dtype=torch.int32, device=dev)
+    cos = torch.empty((n, n), dtype=torch.float32, device=dev) if want_cos else None
+    _lib.call("gdn_topk_graph", _ptr(emb), n, d, k, _ptr(topk), _ptr(nbr), _ptr(deg), _ptr(cos), _stream())
+    return SensorGraph(topk, nbr, deg, cos)
+
+
+def graph_from_topk(topk: torch.Tensor) -> SensorGraph:
+    topk = _chk(topk, torch.int64, "topk")
+    n, k = topk.shape
+    nbr = torch.empty((n, nbr_pitch(k)), dtype=torch.uint16, device=topk.device)
+    deg = torch.empty((n,), dtype=torch.int32, device=topk.device)
+    _lib.call("gdn_graph_from_topk", _ptr(topk), n, k, _ptr(nbr), _ptr(deg), _stream())
+    return SensorGraph(topk, nbr, deg)
+
+
+def node_terms(lin_w, att_i, att_j, att_em_i, att_em_j, emb) -> torch.Tensor:
+    lin_w = _chk(lin_w.detach(), name="lin.weight")
+    d, w = lin_w.shape
+    emb = _chk(emb.detach(), name="embedding")
+    n = emb.shape[0]
+    vs = [_chk(v.detach().reshape(-1), name="att") for v in (att_i, att_j, att_em_i, att_em_j)]
+    out = torch.empty((128 + 2 * n,), dtype=torch.float32, device=emb.device)
+    _lib.call("gdn_node_terms", _ptr(lin_w), *[_ptr(v) for v in vs], _ptr(emb), n, d, w, _ptr(out), _stream())
+    return out
+
+
+def bn_fold(bn: torch.nn.BatchNorm1d) -> torch.Tensor:
+    c = bn.num_features
+    out = torch.empty((2 * c,), dtype=torch.float32, device=bn.weight.device)
+    _lib.call("gdn_bn_fold", _ptr(_chk(bn.weight.detach())), _ptr(_chk(bn.bias.detach())),
+              _ptr(_chk(bn.running_mean)), _ptr(_chk(bn.running_var)), float(bn.eps), c, _ptr(out), _stream())
+    return out
+
+
+def project_fwd(x, lin_w, terms):
+    """x[B,n,w] -> xlin[B*n,d], s_i[B*n], s_j[B*n]  (models/graph_layer.py:56 + logit scalars)."""
+    x = _chk(x, name="x")
+    lin_w = _chk(lin_w.detach(), name="lin.weight")
+    b, n, w = x.shape
+    d = lin_w.shape[0]
+    xlin = torch.empty((b * n, d), dtype=torch.float32, device=x.device)
+    s_i = torch.empty((b * n,), dtype=torch.float32, device=x.device)
+    s_j = torch.empty_like(s_i)
+    _lib.call("gdn_project_fwd", _ptr(x), _ptr(lin_w), _ptr(terms), b, n, w, d,
+              _ptr(xlin), _ptr(s_i), _ptr(s_j), _stream())
+    return xlin, s_i, s_j
+
+
+def attn_aggregate_fwd(xlin, s_i, s_j, graph: SensorGraph, bias, batch: int, want_alpha: bool):
+    """models/graph_layer.py:65-74,82-117 -> z[B*n,d] (+ dense alpha[B*n,pitch])."""
+    xlin = _chk(xlin, name="xlin")
+    bn, d = xlin.shape
+    n = bn // batch
+    z = torch.empty_like(xlin)
+    alpha = torch.empty((bn, graph.pitch), dtype=torch.float32, device=xlin.device) if want_alpha else None
+    _lib.call("gdn_attn_aggregate_fwd", _ptr(xlin), _ptr(_chk(s_i)), _ptr(_chk(s_j)), _ptr(graph.nbr),
+              _ptr(graph.deg), _ptr(_chk(bias.detach())), batch, n, d, graph.k, _ptr(z), _ptr(alpha), _stream())
+    return z, alpha
+
+
+def head_fwd(z, emb, bn1_affine, bn2_affine, out_w, out_b, batch: int, want_h2: bool = False):
+    """Eval head: models/GDN.py:77-79,175-184 with out_layer_num == 1."""
+    z = _chk(z, name="z")
+    bn, d = z.shape
+    n = bn // batch
+    out = torch.empty((batch, n), dtype=torch.float32, device=z.device)
+    h2 = torch.empty_like(z) if want_h2 else None
+    _lib.call("gdn_head_fwd", _ptr(z), _ptr(_chk(emb.detach())), _ptr(bn1_affine), _ptr(bn2_affine),
+              _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
+              batch, n, d, _ptr(out), _ptr(h2), _stream())
+    return out, h2
+
+
+def forward_fused(x, lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
+                  out: torch.Tensor | None = None):
+    """One launch from x[B,n,w] to out[B,n]: models/GDN.py:122-187 under model.eval()."""
+    x = _chk(x, name="x")
+    b, n, w = x.shape
+    lin_w = _chk(lin_w.detach(), name="lin.weight")
+    d = lin_w.shape[0]
+    if out is None:
+        out = torch.empty((b, n), dtype=torch.float32, device=x.device)
+    _lib.call("gdn_forward_fused", _ptr(x), _ptr(lin_w), _ptr(terms), _ptr(graph.nbr), _ptr(graph.deg),
+              _ptr(_chk(gnn_bias.detach())), _ptr(_chk(emb.detach())), _ptr(bn1_affine), _ptr(bn2_affine),
+              _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
+              b, n, w, d, graph.k, _ptr(out), _stream())
+    return out

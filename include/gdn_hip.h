@@ -1,0 +1,154 @@
+/*
+ * gdn_hip.h — C ABI of libgdn_hip.so, the MI355X (gfx950) implementation of GDN's
+ * graph-attention hot path.
+ *
+ * The reference (SchlomoFeng/GDN) has no FFI: its boundary is the Python nn.Module
+ * `GDN.forward(data, org_edge_index)` (models/GDN.py:122-187).  gdn_amd/model.py keeps
+ * that Python API and calls the entry points below through ctypes; each entry point
+ * replaces the reference lines cited at its declaration.  INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the caller allocates every output; the library owns nothing and keeps no state
+ *     between calls (it caches only immutable device properties);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only
+ *     enqueue work, never synchronise, never allocate: they are hipGraph-capturable;
+ *   - return value: GDN_OK (0) or a negative GDN_ERR_* code; nothing is thrown;
+ *   - tensors are dense, row-major, fp32 unless stated; "BN rows" means batch*n rows in
+ *     window-major order (row = b*n + sensor), the layout of models/GDN.py:130;
+ *   - re-entrant across distinct streams.
+ *
+ * Supported shapes: d in {16, 32, 64, 128}; 1 <= w <= 64; 1 <= k <= n <= 4096 with
+ * k+1 <= 1024; anything else returns GDN_ERR_UNSUPPORTED (never a silent fallback).
+ */
+#ifndef GDN_HIP_H
+#define GDN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDN_OK 0
+#define GDN_ERR_ARG (-1)          /* null pointer / non-positive dimension                 */
+#define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
+#define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
+
+#define GDN_ABI_VERSION 1
+int gdn_abi_version(void);
+
+/* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
+int gdn_nbr_pitch(int k);
+
+/* ---- sensor graph -----------------------------------------------------------------
+ * Replaces models/GDN.py:148-159 (cosine matrix, top-k) and the per-forward edge-list
+ * build :161-165 + get_batch_edge_index :15-24 + the self-loop strip/append of
+ * models/graph_layer.py:61-63.  One neighbour list per sensor, shared by every window:
+ *   topk_idx[n,k]  int64, descending cosine, ties -> lower index, NaN ranks highest
+ *                  (= model.learned_graph);
+ *   nbr[n,pitch]   u16: the top-k entries != i in rank order, then i itself, then
+ *                  padding (= i); pitch = gdn_nbr_pitch(k);
+ *   deg[n]         int32: number of valid entries (k, or k+1 when i is not in its own
+ *                  top-k);
+ *   cos_out[n,n]   optional (may be NULL) cosine matrix for inspection.               */
+int gdn_topk_graph(const float* emb, int n, int d, int k,
+                   int64_t* topk_idx, uint16_t* nbr, int32_t* deg, float* cos_out, void* stream);
+
+/* Same neighbour-list build from a GIVEN top-k table (kernel-level parity with an
+ * injected graph; also lets a caller reuse a graph learned elsewhere).                */
+int gdn_graph_from_topk(const int64_t* topk_idx, int n, int k,
+                        uint16_t* nbr, int32_t* deg, void* stream);
+
+/* ---- per-forward constants ----------------------------------------------------------
+ * The attention logit of models/graph_layer.py:91-103 is separable:
+ *   pi(i<-j) = [xlin_i.att_i + v_i.att_em_i] + [xlin_j.att_j + v_j.att_em_j]
+ * and xlin = x.lin^T, so each bracket is  x_row . a + c[sensor]  with
+ *   a_i = lin^T att_i  [w],  c_i[s] = v_s . att_em_i  [n]   (same for _j).
+ * node_terms receives [a_i(64) | a_j(64) | c_i(n) | c_j(n)] (a_* zero padded to 64).   */
+int gdn_node_terms(const float* lin_w, const float* att_i, const float* att_j,
+                   const float* att_em_i, const float* att_em_j, const float* emb,
+                   int n, int d, int w, float* node_terms, void* stream);
+
+/* Eval-mode BatchNorm1d folded to y = x*scale + shift (models/GDN.py:77, :179 under
+ * model.eval()): scale = weight/sqrt(var+eps), shift = bias - mean*scale.
+ * affine receives [scale(c) | shift(c)].                                               */
+int gdn_bn_fold(const float* weight, const float* bias, const float* running_mean,
+                const float* running_var, float eps, int c, float* affine, void* stream);
+
+/* ---- staged forward (training + inspection path) ------------------------------------
+ * gdn_project_fwd: models/graph_layer.py:56 (xlin = x lin^T) plus the two per-node
+ * attention scalars.  x[BN,w] -> xlin[BN,d], s_i[BN], s_j[BN].                         */
+int gdn_project_fwd(const float* x, const float* lin_w, const float* node_terms,
+                    int batch, int n, int w, int d,
+                    float* xlin, float* s_i, float* s_j, void* stream);
+
+/* gdn_attn_aggregate_fwd: models/graph_layer.py:65-74,82-117 + PyG propagate / softmax:
+ * LeakyReLU(0.2) logits, softmax over each target's incoming edges (max-subtract, exp,
+ * /(sum+1e-16)), alpha-weighted sum of source rows, + bias.
+ *   z[BN,d]          aggregate incl. bias (the GraphLayer output);
+ *   alpha[BN,pitch]  optional (NULL to skip): attention weight of nbr slot p of each
+ *                    target row (0 in padding) — att_weight_1 in dense form.           */
+int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const float* s_j,
+                           const uint16_t* nbr, const int32_t* deg, const float* bias,
+                           int batch, int n, int d, int k,
+                           float* z, float* alpha, void* stream);
+
+/* gdn_head_fwd: models/GDN.py:77-79 (BN+ReLU), :175-180 (x embedding, BN+ReLU), eval
+ * dropout = identity (:182), OutLayer with out_layer_num == 1 (:27-56) = Linear(d->1).
+ * bn1_affine / bn2_affine come from gdn_bn_fold.  z[BN,d] -> out[BN].
+ * h2 (optional, NULL to skip) receives the [BN,d] input of the OutLayer (needed when
+ * out_layer_num > 1, whose MLP then runs through gdn_mlp_*).                            */
+int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
+                 const float* bn2_affine, const float* out_w, const float* out_b,
+                 int batch, int n, int d, float* out, float* h2, void* stream);
+
+/* ---- fused eval forward (the throughput path) ---------------------------------------
+ * Everything from x[batch,n,w] to out[batch,n] in one launch (one workgroup per window,
+ * xlin tile and neighbour lists resident in LDS): models/GDN.py:122-187 under
+ * model.eval() with out_layer_num == 1.  HBM traffic = x in + out.                      */
+int gdn_forward_fused(const float* x, const float* lin_w, const float* node_terms,
+                      const uint16_t* nbr, const int32_t* deg, const float* gnn_bias,
+                      const float* emb, const float* bn1_affine, const float* bn2_affine,
+                      const float* out_w, const float* out_b,
+                      int batch, int n, int w, int d, int k, float* out, void* stream);
+
+/* ---- backward (training) -------------------------------------------------------------
+ * Gradients of gdn_attn_aggregate_fwd and gdn_project_fwd; the autograd graph of
+ * `loss.backward()` at train.py:72 restricted to the GraphLayer.  No gradient flows into
+ * the neighbour lists (the graph is built from a detached embedding, models/GDN.py:145).
+ *   d_xlin[BN,d]  (+)= grads from both the message term and nothing else;
+ *   d_si, d_sj    grads of the per-node scalars; d_bias[d] accumulated with atomics
+ *                 (caller zeroes d_bias first).                                         */
+int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
+                           const float* s_i, const float* s_j,
+                           const uint16_t* nbr, const int32_t* deg,
+                           int batch, int n, int d, int k,
+                           float* d_xlin, float* d_si, float* d_sj, float* d_bias, void* stream);
+
+/* x[BN,w], d_xlin[BN,d], d_si/d_sj[BN] -> d_lin_w[d,w] (direct term), d_a[2,64]
+ * (grads of a_i, a_j), d_c[2,n] (grads of c_i, c_j); all accumulated with atomics into
+ * caller-zeroed buffers.                                                                */
+int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
+                    int batch, int n, int w, int d,
+                    float* d_lin_w, float* d_a, float* d_c, void* stream);
+
+/* ---- anomaly scoring -----------------------------------------------------------------
+ * evaluate.py:48-68 + util/data.py:75-82 + the max over sensors of evaluate.py:131-139,
+ * in float64 like the reference.  pred, gt: fp32 [t,n] (time-major, as test.py returns).
+ *   gdn_score_quantiles: per sensor, median and IQR (numpy 'linear' percentiles 25/75)
+ *     of |pred-gt| over all t ticks -> med_iqr[n,2] float64.  workspace: t*n doubles.
+ *   gdn_score_smooth_max: a=(|pred-gt|-med)/(|iqr|+1e-2); 4-tap causal mean (first 3
+ *     ticks 0, taps read `halo` rows before t0 if given); scores[n,t] float64 (optional,
+ *     NULL to skip) and anomaly[t] float64 = max over sensors.                          */
+int gdn_score_quantiles(const float* pred, const float* gt, int t, int n,
+                        double* workspace, double* med_iqr, void* stream);
+int gdn_score_smooth_max(const float* pred, const float* gt, const double* med_iqr,
+                         int t, int n, int first_tick, const float* halo_pred,
+                         const float* halo_gt, double* scores, double* anomaly, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDN_HIP_H */
