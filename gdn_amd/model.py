@@ -148,7 +148,7 @@ class GNNLayer(nn.Module):
         slots = torch.arange(graph.pitch, device=alpha.device).view(1, -1)
         nonself = slots < (deg.view(-1, 1) - 1)                       # [n, pitch]
         self_w = torch.gather(a, 2, (deg - 1).view(1, n, 1).expand(batch, n, 1)).reshape(-1)
-        return torch.cat((a[:, nonself], self_w)).view(-1, 1, 1)
+        return torch.cat((a[:, nonself].reshape(-1), self_w)).view(-1, 1, 1)
 
 
 class OutLayer(nn.Module):

@@ -133,3 +133,30 @@ def forward_fused(x, lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine
               _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
               b, n, w, d, graph.k, _ptr(out), _stream())
     return out
+
+
+def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: int):
+    """Gradient of attn_aggregate_fwd w.r.t. xlin, s_i, s_j and bias."""
+    d_z = _chk(d_z, name="d_z")
+    bn, d = d_z.shape
+    n = bn // batch
+    d_xlin = torch.empty_like(d_z)
+    d_si = torch.empty((bn,), dtype=torch.float32, device=d_z.device)
+    d_sj = torch.empty_like(d_si)
+    d_bias = torch.zeros((d,), dtype=torch.float32, device=d_z.device)
+    _lib.call("gdn_attn_aggregate_bwd", _ptr(d_z), _ptr(_chk(xlin)), _ptr(_chk(alpha)), _ptr(_chk(s_i)),
+              _ptr(_chk(s_j)), _ptr(graph.nbr), _ptr(graph.deg), batch, n, d, graph.k,
+              _ptr(d_xlin), _ptr(d_si), _ptr(d_sj), _ptr(d_bias), _stream())
+    return d_xlin, d_si, d_sj, d_bias
+
+
+def project_bwd(x, d_xlin, d_si, d_sj, d: int):
+    """Gradients of project_fwd: d_lin_w[d,w] (direct term), d_a[2,64], d_c[2,n]."""
+    x = _chk(x, name="x")
+    b, n, w = x.shape
+    d_lin_w = torch.zeros((d, w), dtype=torch.float32, device=x.device)
+    d_a = torch.zeros((2, 64), dtype=torch.float32, device=x.device)
+    d_c = torch.zeros((2, n), dtype=torch.float32, device=x.device)
+    _lib.call("gdn_project_bwd", _ptr(x), _ptr(_chk(d_xlin)), _ptr(_chk(d_si)), _ptr(_chk(d_sj)),
+              b, n, w, d, _ptr(d_lin_w), _ptr(d_a), _ptr(d_c), _stream())
+    return d_lin_w, d_a, d_c
