@@ -28,7 +28,8 @@ SIGNATURES = {
     "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],
     "gdn_attn_aggregate_bwd": [_p] * 7 + [_c_int] * 4 + [_p] * 5,
     "gdn_project_bwd": [_p] * 4 + [_c_int] * 4 + [_p] * 4,
-    # TODO(next commit): gdn_score_quantiles, gdn_score_smooth_max
+    "gdn_score_quantiles": [_p, _p, _c_int, _c_int, _p, _p, _p],
+    "gdn_score_smooth_max": [_p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p],
 }
 
 ERRORS = {-1: "GDN_ERR_ARG (null pointer or non-positive dimension)",

@@ -284,6 +284,18 @@ class GDN(nn.Module):
         h = self.dp(h)                                                      # GDN.py:182
         return self.out_layer(h).view(-1, node_num)                         # GDN.py:183-184
 
+    def forward_into(self, data, out):
+        """Eval fast path writing into a caller-owned [B, N] slice (no allocation, HIP-graph
+        capturable once `_constants()` is warm): used by harness.SeriesEvaluator."""
+        if self.training or self.out_layer_num != 1:
+            raise RuntimeError("forward_into is the eval / out_layer_num == 1 fast path")
+        c = self._constants()
+        gnn = self.gnn_layers[0].gnn
+        lin = self.out_layer.mlp[0]
+        self.learned_graph = c.graph.topk
+        return ops.forward_fused(data, gnn.lin.weight, c.terms, c.graph, gnn.bias, self.embedding.weight,
+                                 c.bn1, c.bn2, lin.weight, lin.bias, out=out)
+
     def _dense_attention(self, x, c, batch):
         gnn = self.gnn_layers[0].gnn
         xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)

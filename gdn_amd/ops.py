@@ -160,3 +160,28 @@ def project_bwd(x, d_xlin, d_si, d_sj, d: int):
     _lib.call("gdn_project_bwd", _ptr(x), _ptr(_chk(d_xlin)), _ptr(_chk(d_si)), _ptr(_chk(d_sj)),
               b, n, w, d, _ptr(d_lin_w), _ptr(d_a), _ptr(d_c), _stream())
     return d_lin_w, d_a, d_c
+
+
+def score_quantiles(pred, gt):
+    """Per-sensor median and IQR of |pred-gt| over all ticks (util/data.py:75-82), float64.
+    pred, gt: fp32 [t, n].  Returns med_iqr[n, 2]."""
+    pred, gt = _chk(pred, name="pred"), _chk(gt, name="gt")
+    t, n = pred.shape
+    ws = torch.empty((n, t), dtype=torch.float64, device=pred.device)
+    out = torch.empty((n, 2), dtype=torch.float64, device=pred.device)
+    _lib.call("gdn_score_quantiles", _ptr(pred), _ptr(gt), t, n, _ptr(ws), _ptr(out), _stream())
+    return out
+
+
+def score_smooth_max(pred, gt, med_iqr, want_scores: bool = True, first_tick: int = 0,
+                     halo_pred=None, halo_gt=None):
+    """evaluate.py:54-68 + the max over sensors of :131-139.  Returns (scores[n,t] | None, anomaly[t])."""
+    pred, gt = _chk(pred, name="pred"), _chk(gt, name="gt")
+    t, n = pred.shape
+    scores = torch.empty((n, t), dtype=torch.float64, device=pred.device) if want_scores else None
+    anomaly = torch.empty((t,), dtype=torch.float64, device=pred.device)
+    hp = None if halo_pred is None else _chk(halo_pred, name="halo_pred")
+    hg = None if halo_gt is None else _chk(halo_gt, name="halo_gt")
+    _lib.call("gdn_score_smooth_max", _ptr(pred), _ptr(gt), _ptr(_chk(med_iqr, torch.float64)), t, n,
+              first_tick, _ptr(hp), _ptr(hg), _ptr(scores), _ptr(anomaly), _stream())
+    return scores, anomaly

@@ -1,0 +1,95 @@
+"""GPU suite: device scoring against the reference's evaluate.py outputs (golden) and against the
+oracle at full size; eval loop (test.py mirror) against the golden eval-loop fixture."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCORE_CASES, load_golden, meta
+from oracle import score_oracle
+from test_gpu_forward_parity import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", SCORE_CASES)
+def test_scores_match_reference_evaluate(case, gpu_device):
+    from gdn_amd import evaluate
+    data, _ = load_golden(case)
+    scores, anomaly, med_iqr = evaluate.anomaly_scores(data["pred"], data["gt"], device=gpu_device)
+    np.testing.assert_allclose(med_iqr.cpu().numpy(), data["med_iqr"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(scores.cpu().numpy(), data["scores"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(anomaly.cpu().numpy(), data["scores"].max(axis=0), rtol=1e-12, atol=1e-13)
+    # the reference-named entry points
+    s2, _ = evaluate.get_full_err_scores([data["pred"].tolist(), data["gt"].tolist(), None], device=gpu_device)
+    np.testing.assert_allclose(s2, data["scores"], rtol=1e-12, atol=1e-13)
+    one = evaluate.get_err_scores((data["pred"][:, 0].tolist(), data["gt"][:, 0].tolist()), device=gpu_device)
+    np.testing.assert_allclose(one, data["scores"][0], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("t,n", [(32768, 127), (4097, 51), (4, 3), (3, 2), (1, 1)])
+def test_scores_full_size_against_oracle(t, n, gpu_device):
+    from gdn_amd import evaluate
+    g = torch.Generator().manual_seed(t + n)
+    pred = torch.rand((t, n), generator=g)
+    gt = (pred + 0.05 * torch.randn((t, n), generator=g)).float()
+    gt[:, 0] = pred[:, 0]                     # a sensor with zero error everywhere: IQR = 0 -> eps only
+    if t > 100:
+        gt[50:60, 1] = pred[50:60, 1] + 3.0   # ties and a burst
+    scores, anomaly, med_iqr = evaluate.anomaly_scores(pred, gt, device=gpu_device)
+    want = score_oracle.full_err_scores(pred.numpy(), gt.numpy()) if t <= 5000 else None
+    for i in (0, 1, n - 1):
+        med, rng = score_oracle.err_median_and_iqr(pred[:, i].numpy(), gt[:, i].numpy())
+        np.testing.assert_allclose(med_iqr[i].cpu().numpy(), [med, rng], rtol=1e-14, atol=0)
+    if want is not None:
+        np.testing.assert_allclose(scores.cpu().numpy(), want, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(anomaly.cpu().numpy(), want.max(axis=0), rtol=1e-12, atol=1e-13)
+    else:
+        # size-independent properties at BASELINE's T: first 3 ticks are 0, anomaly is the max over
+        # sensors, and a few sensors re-scored by the oracle agree
+        s = scores.cpu().numpy()
+        assert (s[:, :3] == 0).all()
+        np.testing.assert_array_equal(anomaly.cpu().numpy(), s.max(axis=0))
+        for i in (0, 1, n // 2):
+            np.testing.assert_allclose(s[i], score_oracle.err_scores(pred[:, i].numpy(), gt[:, i].numpy()),
+                                       rtol=1e-12, atol=1e-13)
+
+
+def test_eval_loop_matches_reference_test_py(gpu_device):
+    """harness.test() on the batches the reference's test() was given."""
+    from gdn_amd import evaluate, harness
+    data, p = load_golden("eval_loop_msl_shape")
+    m = meta(data)
+    model = build_model(p, m, gpu_device)
+    x, y, lab = (torch.from_numpy(data[k]) for k in ("x", "y", "labels"))
+    bsz = m["b"]
+    batches = [(x[s:s + bsz].double(), y[s:s + bsz].double(), lab[s:s + bsz].double(), torch.zeros((bsz, 2, 4)))
+               for s in range(0, x.shape[0], bsz)]
+    avg_loss, (pred, gt, labels) = harness.test(model, batches)
+    np.testing.assert_allclose(np.array(pred), data["pred"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(np.array(gt), data["gt"], atol=0, rtol=0)
+    np.testing.assert_allclose(np.array(labels), data["lab"], atol=0, rtol=0)
+    np.testing.assert_allclose(avg_loss, float(data["avg_loss"]), atol=2e-6)
+    # scoring the REFERENCE's predictions reproduces the reference's scores to float64 round-off
+    scores, _ = evaluate.get_full_err_scores([data["pred"], data["gt"], None], device=gpu_device)
+    np.testing.assert_allclose(scores, data["scores"], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_series_evaluator_equals_per_batch_loop(use_graph, gpu_device):
+    from gdn_amd import evaluate, harness
+    from test_gpu_forward_parity import random_params
+    model = random_params(127, 15, 30, 64, seed=5).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(1)
+    t = 1000                                          # not a multiple of the batch: ragged last launch
+    x = torch.rand((t, 127, 15), generator=g).to(gpu_device)
+    y = torch.rand((t, 127), generator=g).to(gpu_device)
+    ev = harness.SeriesEvaluator(model, x, y, batch=128, use_graph=use_graph, want_scores=True)
+    a1 = ev.step().clone()
+    a2 = ev.step().clone()                             # replay must be idempotent
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2)
+    with torch.no_grad():
+        pred = torch.cat([model(x[s:s + 128], None) for s in range(0, t, 128)])
+    assert torch.equal(pred, ev.pred)
+    _, anomaly, _ = evaluate.anomaly_scores(pred, y, device=gpu_device)
+    assert torch.equal(anomaly, a1)
