@@ -189,8 +189,7 @@ extern "C" int gdn_score_smooth_max(const float* pred, const float* gt, const do
                                     int first_tick, const float* halo_pred, const float* halo_gt,
                                     double* scores, double* anomaly, void* stream) {
   if (!pred || !gt || !med_iqr || !anomaly || t <= 0 || n <= 0 || first_tick < 0) return GDN_ERR_ARG;
-  if (first_tick > 0 && first_tick < 3) return GDN_ERR_UNSUPPORTED;  // shards start at tick 0 or >= 3
-  if (first_tick >= 3 && (!halo_pred || !halo_gt)) return GDN_ERR_ARG;
+  if (first_tick > 0 && (!halo_pred || !halo_gt)) return GDN_ERR_ARG;
   const int grid = min((t + 3) / 4, gdn_cu_count() * 8);
   hipLaunchKernelGGL(score_smooth_max_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, gt,
                      med_iqr, t, n, first_tick, halo_pred, halo_gt, scores, anomaly);

@@ -180,7 +180,8 @@ def distributed_anomaly(pred_local, gt_local, total_ticks: int, backend=HipScore
     gathered = [torch.empty_like(padded) for _ in range(size)]
     dist.all_gather(gathered, padded, group=group)
     med_iqr = torch.cat([g[: b - a] for g, (a, b) in zip(gathered, sens)]).contiguous()
-    # ---- step 3: halo = last 3 rows of the previous rank
+    # ---- step 3: halo = the 3 ticks before my first one.  Every rank publishes its last <=3 rows
+    # (right-aligned); a shard shorter than 3 ticks makes the halo span several predecessors.
     tail = torch.zeros((2, 3, n), dtype=pred_local.dtype, device=dev)
     take = min(3, t_local)
     if take:
@@ -190,8 +191,14 @@ def distributed_anomaly(pred_local, gt_local, total_ticks: int, backend=HipScore
     dist.all_gather(tails, tail, group=group)
     first_tick = bounds[rank][0]
     halo_p = halo_g = None
-    if rank > 0:
-        halo_p, halo_g = tails[rank - 1][0].contiguous(), tails[rank - 1][1].contiguous()
+    if first_tick > 0:
+        rows = [torch.zeros((2, 3, n), dtype=pred_local.dtype, device=dev)]   # ticks "before 0": never read
+        for r in range(rank):
+            have = min(3, bounds[r][1] - bounds[r][0])
+            if have:
+                rows.append(tails[r][:, 3 - have:])
+        prev = torch.cat(rows, dim=1)[:, -3:]
+        halo_p, halo_g = prev[0].contiguous(), prev[1].contiguous()
     if t_local == 0:
         return torch.empty((0,), dtype=torch.float64, device=dev)
     return backend.smooth_max(pred_local, gt_local, med_iqr, first_tick, halo_p, halo_g)

@@ -140,8 +140,10 @@ int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, cons
  *   gdn_score_quantiles: per sensor, median and IQR (numpy 'linear' percentiles 25/75)
  *     of |pred-gt| over all t ticks -> med_iqr[n,2] float64.  workspace: t*n doubles.
  *   gdn_score_smooth_max: a=(|pred-gt|-med)/(|iqr|+1e-2); 4-tap causal mean (first 3
- *     ticks 0, taps read `halo` rows before t0 if given); scores[n,t] float64 (optional,
- *     NULL to skip) and anomaly[t] float64 = max over sensors.                          */
+ *     ticks of the SERIES 0); `first_tick` = series index of row 0 of this shard; when it is
+ *     > 0, halo_pred/halo_gt [3,n] hold the 3 rows before it (right aligned; rows that would
+ *     precede tick 0 are never read); scores[n,t] float64 (optional, NULL to skip) and
+ *     anomaly[t] float64 = max over sensors.                                            */
 int gdn_score_quantiles(const float* pred, const float* gt, int t, int n,
                         double* workspace, double* med_iqr, void* stream);
 int gdn_score_smooth_max(const float* pred, const float* gt, const double* med_iqr,

@@ -1,0 +1,81 @@
+"""Worker for tests/test_cpu_distributed.py: run under torch.distributed.run with gloo, 2 ranks.
+Exercises the N>1 host logic on CPU: shard split, the all-to-all-by-sensor scoring exchange and the
+flat-bucket gradient all-reduce.  The per-rank arithmetic is injected from the oracle (tests may do
+that; the product default is the HIP backend)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gdn_amd import harness  # noqa: E402
+from oracle import score_oracle  # noqa: E402
+
+
+class OracleScoreBackend:
+    @staticmethod
+    def quantiles(pred_tn, gt_tn):
+        rows = [score_oracle.err_median_and_iqr(pred_tn[:, i].numpy(), gt_tn[:, i].numpy())
+                for i in range(pred_tn.shape[1])]
+        return torch.tensor(rows, dtype=torch.float64).reshape(-1, 2)
+
+    @staticmethod
+    def smooth_max(pred_tn, gt_tn, med_iqr, first_tick, halo_pred, halo_gt):
+        p, g = pred_tn.double().numpy(), gt_tn.double().numpy()
+        if halo_pred is not None:
+            p = np.concatenate([halo_pred.double().numpy(), p])
+            g = np.concatenate([halo_gt.double().numpy(), g])
+        pad = p.shape[0] - pred_tn.shape[0]
+        mi = med_iqr.numpy()
+        a = (np.abs(p - g) - mi[:, 0]) / (np.abs(mi[:, 1]) + 1e-2)
+        out = np.zeros((pred_tn.shape[0], p.shape[1]))
+        for t in range(pred_tn.shape[0]):
+            if first_tick + t >= 3:
+                r = t + pad
+                out[t] = (((a[r - 3] + a[r - 2]) + a[r - 1]) + a[r]) / 4.0
+        return torch.from_numpy(out.max(axis=1))
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    for total, n in ((101, 7), (64, 5), (9, 3), (5, 2)):
+        g = torch.Generator().manual_seed(total)
+        pred = torch.rand((total, n), generator=g)
+        gt = pred + 0.1 * torch.randn((total, n), generator=g)
+        s, e = harness.shard_range(total, rank, size)
+        local = harness.distributed_anomaly(pred[s:e].contiguous(), gt[s:e].contiguous(), total,
+                                            backend=OracleScoreBackend)
+        want = score_oracle.anomaly_score(score_oracle.full_err_scores(pred.numpy(), gt.numpy()))
+        np.testing.assert_allclose(local.numpy(), want[s:e], rtol=1e-12, atol=1e-13)
+
+    # flat-bucket gradient averaging
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3), torch.nn.Linear(3, 1))
+    harness.broadcast_parameters(model)
+    x = torch.full((4, 5), float(rank + 1))
+    model(x).sum().backward()
+    mine = [p.grad.clone() for p in model.parameters()]
+    gathered = [[torch.empty_like(m) for _ in range(size)] for m in mine]
+    for buf, m in zip(gathered, mine):
+        dist.all_gather(buf, m)
+    harness.sync_gradients(model)
+    for p, buf in zip(model.parameters(), gathered):
+        torch.testing.assert_close(p.grad, sum(buf) / size)
+    # identical parameters on every rank after the broadcast
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(flat, ref)
+    dist.barrier()
+    if rank == 0:
+        print("DIST_WORKER_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

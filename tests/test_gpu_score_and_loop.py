@@ -37,7 +37,7 @@ def test_scores_full_size_against_oracle(t, n, gpu_device):
         gt[50:60, 1] = pred[50:60, 1] + 3.0   # ties and a burst
     scores, anomaly, med_iqr = evaluate.anomaly_scores(pred, gt, device=gpu_device)
     want = score_oracle.full_err_scores(pred.numpy(), gt.numpy()) if t <= 5000 else None
-    for i in (0, 1, n - 1):
+    for i in sorted({0, min(1, n - 1), n - 1}):
         med, rng = score_oracle.err_median_and_iqr(pred[:, i].numpy(), gt[:, i].numpy())
         np.testing.assert_allclose(med_iqr[i].cpu().numpy(), [med, rng], rtol=1e-14, atol=0)
     if want is not None:

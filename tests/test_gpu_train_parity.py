@@ -76,6 +76,6 @@ def test_two_adam_steps_match_reference_train_loop(gpu_device):
         if key == "gnn_layers.0.gnn.bias":
             # this bias feeds a train-mode BatchNorm, so its true gradient is exactly 0 and both
             # implementations see only rounding noise (~1e-9), which Adam turns into +-lr steps:
-            # after 2 steps the values may differ by up to 2*lr
-            atol = 2.5e-3
+            # each step the two runs may move in opposite directions: up to ~2*lr apart per step
+            atol = 4.5e-3
         np.testing.assert_allclose(val.cpu().numpy(), data["p_final/" + key], atol=atol, rtol=0, err_msg=key)
