@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void gdn_attn_bwd_kernel(
     const int nvec = pl.n * pl.pitch / 8;
     for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
   }
-  for (int t = tid; t < D; t += nth) dbias[t] = 0.f;
+  for (int t = tid; t < D; t += nth) {
+    dbias[t] = 0.f;
+    xl[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
+  }
+  if (tid == 0) sj[pl.n] = 0.f;
   PackB<G::VEC> bias_acc;
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] = 0.f;
@@ -286,10 +290,10 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
   if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
   BwdPlan pl;
   pl.n = n; pl.d = d; pl.k = k; pl.batch = batch; pl.pitch = gdn_nbr_pitch(k);
-  const int npad = (n + 3) & ~3;
+  const int npad = (n + 1 + 3) & ~3;   // +1: the sentinel index n used as list padding
   int off = 0;
-  pl.off_xl = off; off += n * d;
-  pl.off_dxl = off; off += n * d;
+  pl.off_xl = off; off += (n + 1) * d;
+  pl.off_dxl = off; off += (n + 1) * d;
   pl.off_sj = off; off += npad;
   pl.off_dsj = off; off += npad;
   pl.off_dbias = off; off += d;

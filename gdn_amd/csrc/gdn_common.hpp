@@ -59,7 +59,8 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * GDN_NEG_SLOPE; }
+// LeakyReLU(0.2): max(v, 0.2 v) — v for v > 0, 0.2 v otherwise; -inf stays -inf
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, v * GDN_NEG_SLOPE); }
 
 // 64-lane wave sum through DPP + readlane (used by the small reduction kernels).
 __device__ __forceinline__ float wave_sum(float v) {

@@ -18,6 +18,10 @@
 // order of the sum differs per lane, the set does not.
 #include "gdn_common.hpp"
 
+#ifndef GDN_GATHER_CHUNK
+#define GDN_GATHER_CHUNK 8
+#endif
+
 namespace {
 
 template <int V>
@@ -63,7 +67,8 @@ struct Plan {
   int n, d, w, wp, k, pitch, batch;
   int xrows;     // rows of x staged per chunk (project / fused)
   int nbr_lds;   // 1: neighbour lists in LDS, 0: read through L2
-  int off_xl, off_si, off_sj, off_deg, off_nbr, off_xs;  // float offsets
+  int wl_lds;    // 1: lin.weight staged (permuted) in LDS, 0: lane blocks loaded from global
+  int off_xl, off_si, off_sj, off_deg, off_wl, off_nbr, off_xs;  // float offsets
   int lds_bytes;
 };
 
@@ -95,19 +100,54 @@ struct Args {
 };
 
 // ------------------------------------------------------------------ projection phase
-// This lane's [VEC x WCH] block of lin.weight for W-chunk wc (zero beyond w).
+// lin.weight lives in LDS for the whole workgroup, permuted so that a lane fetches its
+// [VEC x WCH] block for W-chunk wc with conflict-free ds_read_b128:
+//   float4 index = ((wc * VEC + v) * (WCH/4) + c4) * (D/VEC) + lane_slot,   lane_slot = d0 / VEC
+// (consecutive lanes -> consecutive 16-B slots).  Columns >= w are stored as 0.
 template <int D, int WCH>
-__device__ __forceinline__ void load_lane_weights(const Plan& pl, const Args& a, int wc,
+__device__ __forceinline__ void stage_weights(const Plan& pl, const Args& a, float* wlds) {
+  using G = Geo<D>;
+  constexpr int LS = D / G::VEC;  // lane slots
+  const int total = D * pl.wp;     // floats
+  for (int t = threadIdx.x; t < total; t += blockDim.x) {
+    const int e = t & 3;                 // element of the float4
+    const int q = t >> 2;
+    const int slot = q % LS;
+    const int r = q / LS;                // (wc * VEC + v) * (WCH/4) + c4
+    const int c4 = r % (WCH / 4);
+    const int vv = (r / (WCH / 4)) % G::VEC;
+    const int wc = r / ((WCH / 4) * G::VEC);
+    const int col = wc * WCH + c4 * 4 + e;
+    const int drow = slot * G::VEC + vv;
+    wlds[t] = col < pl.w ? a.lin_w[(size_t)drow * pl.w + col] : 0.f;
+  }
+}
+
+template <int D, int WCH>
+__device__ __forceinline__ void load_lane_weights(const Plan& pl, const Args& a, const float* wlds, int wc,
                                                   float (&wl)[Geo<D>::VEC][WCH]) {
   using G = Geo<D>;
+  constexpr int LS = D / G::VEC;
   const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-  const int d0 = (grp % G::NS) * 64 + l16 * G::VEC;
+  const int slot = (grp % G::NS) * 16 + l16;
+  if (!pl.wl_lds) {   // big tiles: no LDS to spare, read the block through L2
+    const int d0 = slot * G::VEC;
+#pragma unroll
+    for (int v = 0; v < G::VEC; ++v)
+#pragma unroll
+      for (int c = 0; c < WCH; ++c) {
+        const int col = wc * WCH + c;
+        wl[v][c] = col < pl.w ? a.lin_w[(size_t)(d0 + v) * pl.w + col] : 0.f;
+      }
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v)
 #pragma unroll
-    for (int c = 0; c < WCH; ++c) {
-      const int col = wc * WCH + c;
-      wl[v][c] = col < pl.w ? a.lin_w[(size_t)(d0 + v) * pl.w + col] : 0.f;
+    for (int c4 = 0; c4 < WCH / 4; ++c4) {
+      const float4 t = *reinterpret_cast<const float4*>(
+          wlds + ((size_t)((wc * G::VEC + v) * (WCH / 4) + c4) * LS + slot) * 4);
+      wl[v][c4 * 4] = t.x; wl[v][c4 * 4 + 1] = t.y; wl[v][c4 * 4 + 2] = t.z; wl[v][c4 * 4 + 3] = t.w;
     }
 }
 
@@ -177,22 +217,137 @@ __device__ __forceinline__ void project_chunk(const Plan& pl, const Args& a, flo
 }
 
 // ------------------------------------------------------------------ attention + aggregation
-template <int D, int MODE>
+// acc += alpha_q * xlin[j_q] for the 16 neighbours q held by the lanes of this row.  Step S uses
+// the pair rotated by S lanes; every rotation is taken from the ORIGINAL registers (row_ror:S), so
+// the 16 LDS addresses are independent and all 16 ds_read_b128 can be in flight at once.
+template <int D, int S>
+__device__ __forceinline__ void gather_steps(const char* xl_lane, float al, int jb,
+                                             Pack<Geo<D>::VEC>& acc) {
+  using G = Geo<D>;
+  if constexpr (S < 16) {
+    float a_s;
+    int j_s;
+    if constexpr (S == 0) {
+      a_s = al;
+      j_s = jb;
+    } else {
+      a_s = dpp_f<0x120 + S>(al);
+      j_s = dpp_i<0x120 + S>(jb);
+    }
+    const Pack<G::VEC> src = ld_pack<G::VEC>(reinterpret_cast<const float*>(xl_lane + j_s));
+#pragma unroll
+    for (int v = 0; v < G::VEC; ++v) acc.v[v] = fmaf(a_s, src.v[v], acc.v[v]);
+    // keep at most GDN_GATHER_CHUNK row fetches in flight: bounds the VGPRs the scheduler may spend
+    if constexpr ((S + 1) % GDN_GATHER_CHUNK == 0 && S + 1 < 16) __builtin_amdgcn_sched_barrier(0);
+    gather_steps<D, S + 1>(xl_lane, al, jb, acc);
+  }
+}
+
+struct AggCtx {
+  const float* si;
+  const float* sj;
+  const uint16_t* degs;
+  const uint16_t* nbr;
+  const char* xl_lane;
+};
+
+// Softmax weights + weighted neighbour sum of ONE target row.  MAXR > 0: the target has at most
+// MAXR rounds of 16 neighbours and logits stay in registers; MAXR == 0: any length, logits are
+// recomputed per pass.  Returns the aggregate (without bias) in `acc`.
+template <int D, int MODE, int MAXR>
+__device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, const AggCtx& c, int b, int i,
+                                                 int slice, int l16, Pack<Geo<D>::VEC>& acc) {
+  using G = Geo<D>;
+  const int degi = c.degs[i];
+  const int rounds = (degi + 15) >> 4;
+  const float sti = c.si[i];
+  const uint16_t* nrow = c.nbr + (size_t)i * pl.pitch;
+  float* arow = nullptr;
+  if constexpr (MODE == MODE_ATTN) {
+    if (a.alpha && slice == 0) arow = a.alpha + ((size_t)b * pl.n + i) * pl.pitch;
+  }
+#pragma unroll
+  for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
+
+  if constexpr (MAXR > 0) {
+    // padding slots hold the sentinel index n: sj[n] = -inf (weight 0) and tile row n = 0, so no
+    // per-lane validity test is needed
+    int jn[MAXR];
+    float e[MAXR];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) jn[r] = r < rounds ? (int)nrow[r * 16 + l16] : pl.n;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      e[r] = leaky(sti + c.sj[jn[r]]);
+      m = fmaxf(m, e[r]);
+    }
+    m = row16_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      e[r] = __expf(e[r] - m);   // exp(-inf) = 0 in the padding slots
+      sum += e[r];
+    }
+    sum = row16_sum(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum + GDN_SOFTMAX_EPS);
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      if (r < rounds) {
+        const float al = e[r] * inv;
+        if constexpr (MODE == MODE_ATTN) {
+          if (arow) arow[r * 16 + l16] = al;
+        }
+        gather_steps<D, 0>(c.xl_lane, al, jn[r] * (D * 4), acc);
+      }
+    }
+  } else {
+    float m = -INFINITY;
+    for (int r = 0; r < rounds; ++r) {
+      const int p = r * 16 + l16;
+      m = fmaxf(m, leaky(sti + c.sj[nrow[p]]));
+    }
+    m = row16_max(m);
+    float sum = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+      const int p = r * 16 + l16;
+      sum += __expf(leaky(sti + c.sj[nrow[p]]) - m);
+    }
+    sum = row16_sum(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum + GDN_SOFTMAX_EPS);
+    for (int r = 0; r < rounds; ++r) {
+      const int p = r * 16 + l16;
+      const int j = nrow[p];
+      const float al = __expf(leaky(sti + c.sj[j]) - m) * inv;
+      if constexpr (MODE == MODE_ATTN) {
+        if (arow) arow[p] = al;
+      }
+      gather_steps<D, 0>(c.xl_lane, al, j * (D * 4), acc);
+    }
+  }
+  if constexpr (MODE == MODE_ATTN) {
+    // zero the alpha slots of rounds this target does not use
+    if (arow)
+      for (int p = rounds * 16 + l16; p < pl.pitch; p += 16) arow[p] = 0.f;
+  }
+}
+
+template <int D, int MODE, int MAXR>
 __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, float* smem, int b) {
   using G = Geo<D>;
   const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
   const int slot = grp / G::NS, slice = grp % G::NS;
   const int tpp = (blockDim.x >> 4) / G::NS;
   const int d0 = slice * 64 + l16 * G::VEC;
-  const float* xl = smem + pl.off_xl;
-  const float* si = smem + pl.off_si;
-  const float* sj = smem + pl.off_sj;
-  const uint16_t* degs = reinterpret_cast<const uint16_t*>(smem + pl.off_deg);
-  const uint16_t* nbr = pl.nbr_lds ? reinterpret_cast<const uint16_t*>(smem + pl.off_nbr) : a.nbr;
-  const char* xl_lane = reinterpret_cast<const char*>(xl + d0);
+  AggCtx c;
+  c.si = smem + pl.off_si;
+  c.sj = smem + pl.off_sj;
+  c.degs = reinterpret_cast<const uint16_t*>(smem + pl.off_deg);
+  c.nbr = pl.nbr_lds ? reinterpret_cast<const uint16_t*>(smem + pl.off_nbr) : a.nbr;
+  c.xl_lane = reinterpret_cast<const char*>(smem + pl.off_xl + d0);
 
   // per-lane constants of the epilogue
-  Pack<G::VEC> bias = ld_pack<G::VEC>(a.gnn_bias + d0);
+  const Pack<G::VEC> bias = ld_pack<G::VEC>(a.gnn_bias + d0);
   Pack<G::VEC> sc1, sh1, sc2, sh2, wo;
   float out_b = 0.f;
   if constexpr (MODE == MODE_FUSED) {
@@ -205,60 +360,10 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
   }
 
   for (int i = slot; i < pl.n; i += tpp) {
-    const int degi = degs[i];
-    const int rounds = (degi + 15) >> 4;
-    const float sti = si[i];
-    const uint16_t* nrow = nbr + (size_t)i * pl.pitch;
     Pack<G::VEC> emb_i;
     if constexpr (MODE == MODE_FUSED) emb_i = ld_pack<G::VEC>(a.emb + (size_t)i * D + d0);
-
-    // pass 1: row max of LeakyReLU(s_i[i] + s_j[src])
-    float m = -INFINITY;
-    for (int r = 0; r < rounds; ++r) {
-      const int p = r * 16 + l16;
-      const float e = leaky(sti + sj[nrow[p]]);
-      m = fmaxf(m, p < degi ? e : -INFINITY);
-    }
-    m = row16_max(m);
-    // pass 2: denominator
-    float sum = 0.f;
-    for (int r = 0; r < rounds; ++r) {
-      const int p = r * 16 + l16;
-      const float e = leaky(sti + sj[nrow[p]]);
-      sum += p < degi ? expf(e - m) : 0.f;
-    }
-    sum = row16_sum(sum);
-    const float inv = 1.f / (sum + GDN_SOFTMAX_EPS);
-
-    // pass 3: alpha-weighted sum of source rows
     Pack<G::VEC> acc;
-#pragma unroll
-    for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
-    for (int r = 0; r < rounds; ++r) {
-      const int p = r * 16 + l16;
-      const int j = nrow[p];
-      const float e = leaky(sti + sj[j]);
-      float al = p < degi ? expf(e - m) * inv : 0.f;
-      int jb = j * (D * 4);
-      if constexpr (MODE == MODE_ATTN) {
-        if (a.alpha && slice == 0) a.alpha[((size_t)b * pl.n + i) * pl.pitch + p] = al;
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const Pack<G::VEC> src = ld_pack<G::VEC>(reinterpret_cast<const float*>(xl_lane + jb));
-#pragma unroll
-        for (int v = 0; v < G::VEC; ++v) acc.v[v] = fmaf(al, src.v[v], acc.v[v]);
-        al = dpp_f<GDN_DPP_ROR1>(al);
-        jb = dpp_i<GDN_DPP_ROR1>(jb);
-      }
-    }
-    if constexpr (MODE == MODE_ATTN) {
-      // zero the alpha slots of rounds this target does not use
-      if (a.alpha && slice == 0)
-        for (int p = rounds * 16 + l16; p < pl.pitch; p += 16)
-          a.alpha[((size_t)b * pl.n + i) * pl.pitch + p] = 0.f;
-    }
-
+    aggregate_target<D, MODE, MAXR>(pl, a, c, b, i, slice, l16, acc);
 #pragma unroll
     for (int v = 0; v < G::VEC; ++v) acc.v[v] += bias.v[v];
     if constexpr (MODE == MODE_ATTN) {
@@ -279,8 +384,50 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
   }
 }
 
+// neighbour-list length class: <=2 rounds (k <= 31) and <=5 rounds (k <= 79) keep logits in
+// registers; longer lists take the recompute path.
+template <int D, int MODE>
+__device__ __forceinline__ void aggregate_dispatch(const Plan& pl, const Args& a, float* smem, int b) {
+  if (pl.pitch <= 32) aggregate_window<D, MODE, 2>(pl, a, smem, b);
+  else if (pl.pitch <= 80) aggregate_window<D, MODE, 5>(pl, a, smem, b);
+  else aggregate_window<D, MODE, 0>(pl, a, smem, b);
+}
+
 // ------------------------------------------------------------------ the kernel
-// Stage rows [r0, r1) of x[b] into LDS at pitch wp (zero padded columns).
+// x staging, split into "issue the global loads" and "store to LDS" (async-STAGE split): the
+// loads of window b+1 are issued before window b's projection/aggregation and land under them.
+// Lane (t & (wp-1)) owns column c of a row, so no division is needed; columns >= w are stored as 0.
+// Fast form: wp <= 16 and at most 8 rows per thread per window (n <= 8 * blockDim/wp).
+struct XRegs {
+  float v[8];
+};
+
+__device__ __forceinline__ void stage_x_load(const Plan& pl, const float* xg, XRegs& xr) {
+  const int c = threadIdx.x & (pl.wp - 1);
+  const int rstep = blockDim.x / pl.wp;
+  const int r = threadIdx.x / pl.wp;
+  const bool live = c < pl.w;
+  const int cc = live ? c : 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int rr = min(r + u * rstep, pl.n - 1);
+    const float t = xg[(size_t)rr * pl.w + cc];   // unconditional (clamped) load: stays in registers
+    xr.v[u] = live ? t : 0.f;
+  }
+}
+
+__device__ __forceinline__ void stage_x_store(const Plan& pl, float* xs, const XRegs& xr) {
+  const int c = threadIdx.x & (pl.wp - 1);
+  const int rstep = blockDim.x / pl.wp;
+  const int r = threadIdx.x / pl.wp;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int rr = r + u * rstep;
+    if (rr < pl.n) xs[rr * pl.wp + c] = xr.v[u];
+  }
+}
+
+// General form: rows [r0, r1), any wp.
 __device__ __forceinline__ void stage_x(const Plan& pl, const float* xg, float* xs, int r0, int r1) {
   const int cnt = (r1 - r0) * pl.wp;
   for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
@@ -296,10 +443,13 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
   float* smem = reinterpret_cast<float*>(smem_f4);
   const int tid = threadIdx.x, nth = blockDim.x;
 
-  // once per workgroup: neighbour lists + degrees into LDS
+  // once per workgroup: neighbour lists + degrees into LDS; sentinel row n of the tile = 0 and
+  // s_j[n] = -inf (the padding slots of every neighbour list point there)
   if constexpr (MODE != MODE_PROJECT) {
     uint16_t* degs = reinterpret_cast<uint16_t*>(smem + pl.off_deg);
     for (int t = tid; t < pl.n; t += nth) degs[t] = (uint16_t)a.deg[t];
+    for (int t = tid; t < D; t += nth) smem[pl.off_xl + pl.n * D + t] = 0.f;
+    if (tid == 0) smem[pl.off_sj + pl.n] = -INFINITY;
     if (pl.nbr_lds) {
       // n*pitch u16 = n*pitch/8 uint4 (pitch is a multiple of 16)
       const uint4* src = reinterpret_cast<const uint4*>(a.nbr);
@@ -310,36 +460,89 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
   }
 
   if constexpr (MODE == MODE_ATTN) {
-    for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
-      // stage xlin[b] (n*d floats, 16-B vectors) and the node scalars
-      const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)b * pl.n * D);
-      float4* dst = reinterpret_cast<float4*>(smem + pl.off_xl);
-      const int nvec = pl.n * D / 4;
-      for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
-      float* si = smem + pl.off_si;
-      float* sj = smem + pl.off_sj;
-      for (int t = tid; t < pl.n; t += nth) {
-        si[t] = a.si_in[(size_t)b * pl.n + t];
-        sj[t] = a.sj_in[(size_t)b * pl.n + t];
+    // Tile staging is split (async-STAGE): the global loads of window b+1 are issued BEFORE window
+    // b's aggregation and stored to LDS after it, so HBM latency hides under the math even when
+    // all workgroups of a CU run in lockstep.  Fast form: n*D/4 float4s <= 8 per thread.
+    float4* tile4 = reinterpret_cast<float4*>(smem + pl.off_xl);
+    float* si = smem + pl.off_si;
+    float* sj = smem + pl.off_sj;
+    const int nvec = pl.n * D / 4;
+    const bool fast = nvec <= 8 * nth && pl.n <= nth;
+    if (fast) {
+      // eight named registers (an array here is demoted to scratch by the compiler); loads are
+      // unconditional with a clamped index, only the LDS store is predicated
+      float4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;
+      float psi, psj;
+      const int tn = min(tid, pl.n - 1);
+#define GDN_PRE_LOAD(u) pre##u = src[min(tid + u * nth, nvec - 1)];
+#define GDN_PRE_STORE(u)              \
+  {                                   \
+    const int t = tid + u * nth;      \
+    if (t < nvec) tile4[t] = pre##u;  \
+  }
+#define GDN_PRE_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+      {
+        const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)blockIdx.x * pl.n * D);
+        GDN_PRE_ALL(GDN_PRE_LOAD)
+        psi = a.si_in[(size_t)blockIdx.x * pl.n + tn];
+        psj = a.sj_in[(size_t)blockIdx.x * pl.n + tn];
       }
-      __syncthreads();
-      aggregate_window<D, MODE>(pl, a, smem, b);
-      __syncthreads();  // the tile is overwritten by the next window
+      for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
+        GDN_PRE_ALL(GDN_PRE_STORE)
+        if (tid < pl.n) {
+          si[tid] = psi;
+          sj[tid] = psj;
+        }
+        __syncthreads();
+        const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round re-reads its own tile
+        {
+          const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)nb * pl.n * D);
+          GDN_PRE_ALL(GDN_PRE_LOAD)
+          psi = a.si_in[(size_t)nb * pl.n + tn];
+          psj = a.sj_in[(size_t)nb * pl.n + tn];
+        }
+        aggregate_dispatch<D, MODE>(pl, a, smem, b);
+        __syncthreads();  // the tile is overwritten by the next window
+      }
+#undef GDN_PRE_ALL
+#undef GDN_PRE_STORE
+#undef GDN_PRE_LOAD
+    } else {
+      for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
+        const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)b * pl.n * D);
+        for (int t = tid; t < nvec; t += nth) tile4[t] = src[t];
+        for (int t = tid; t < pl.n; t += nth) {
+          si[t] = a.si_in[(size_t)b * pl.n + t];
+          sj[t] = a.sj_in[(size_t)b * pl.n + t];
+        }
+        __syncthreads();
+        aggregate_dispatch<D, MODE>(pl, a, smem, b);
+        __syncthreads();
+      }
     }
   } else {
     float* xs = smem + pl.off_xs;
+    float* wlds = smem + pl.off_wl;
     const int nch = pl.wp / WCH;
-    if (nch == 1 && pl.xrows >= pl.n) {
-      // common case (w <= 16, whole window in one x chunk): lin.weight block stays in registers
-      float wl[G::VEC][WCH];
-      load_lane_weights<D, WCH>(pl, a, 0, wl);
+    if (pl.wl_lds) stage_weights<D, WCH>(pl, a, wlds);
+    // (visibility of wlds: the first __syncthreads() below precedes its first read)
+    const bool fast = nch == 1 && pl.xrows >= pl.n && pl.n <= 8 * (int)(blockDim.x / pl.wp);
+    if (fast) {
+      XRegs xr;
+      stage_x_load(pl, a.x + (size_t)blockIdx.x * pl.n * pl.w, xr);
       for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
-        stage_x(pl, a.x + (size_t)b * pl.n * pl.w, xs, 0, pl.n);
+        stage_x_store(pl, xs, xr);
         __syncthreads();
-        project_chunk<D, WCH, MODE == MODE_PROJECT>(pl, a, smem, b, 0, pl.n, 0, 1, wl);
+        const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round: harmless re-read
+        stage_x_load(pl, a.x + (size_t)nb * pl.n * pl.w, xr);   // lands under the math
+        {
+          float wl[G::VEC][WCH];
+          load_lane_weights<D, WCH>(pl, a, wlds, 0, wl);
+          project_chunk<D, WCH, MODE == MODE_PROJECT>(pl, a, smem, b, 0, pl.n, 0, 1, wl);
+        }
         __syncthreads();
         if constexpr (MODE == MODE_FUSED) {
-          aggregate_window<D, MODE>(pl, a, smem, b);
+          aggregate_dispatch<D, MODE>(pl, a, smem, b);
           __syncthreads();
         }
       }
@@ -350,14 +553,16 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           stage_x(pl, a.x + (size_t)b * pl.n * pl.w, xs, r0, r1);
           __syncthreads();
           for (int wc = 0; wc < nch; ++wc) {
+            // the weight block is re-read from LDS every time instead of living in 64 VGPRs
+            // across the aggregation phase
             float wl[G::VEC][WCH];
-            load_lane_weights<D, WCH>(pl, a, wc, wl);
+            load_lane_weights<D, WCH>(pl, a, wlds, wc, wl);
             project_chunk<D, WCH, MODE == MODE_PROJECT>(pl, a, smem, b, r0, r1, wc, nch, wl);
           }
           __syncthreads();
         }
         if constexpr (MODE == MODE_FUSED) {
-          aggregate_window<D, MODE>(pl, a, smem, b);
+          aggregate_dispatch<D, MODE>(pl, a, smem, b);
           __syncthreads();
         }
       }
@@ -421,12 +626,18 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
     pl->pitch = gdn_nbr_pitch(k);
   }
   const int LDS_MAX = 160 * 1024;
-  const int npad = (n + 3) & ~3;
+  const int npad = (n + 1 + 3) & ~3;   // +1: sentinel entry / row
   int off = 0;
-  pl->off_xl = off; off += n * d;
+  pl->off_xl = off; off += (n + 1) * d;
   pl->off_si = off; off += npad;
   pl->off_sj = off; off += npad;
   pl->off_deg = off; off += (npad / 2 + 3) & ~3;
+  pl->off_wl = off;
+  pl->wl_lds = 0;
+  if (mode != MODE_ATTN && (off + d * pl->wp) * 4 + 16 * pl->wp * 4 + 2048 <= LDS_MAX / 2) {
+    pl->wl_lds = 1;                               // small tiles: keep the weights beside them
+    off += d * pl->wp;
+  }
   pl->off_nbr = off;
   pl->off_xs = off;
   int fixed = off * 4;

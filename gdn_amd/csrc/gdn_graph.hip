@@ -21,7 +21,8 @@ __device__ __forceinline__ bool ranks_before(float a, int ia, float b, int ib) {
 }
 
 // Neighbour list of target i from the ranks of all sensors (rank < k = member of top-k):
-// entries != i keep their rank order, then i itself (models/graph_layer.py:61-63), padding = i.
+// entries != i keep their rank order, then i itself (models/graph_layer.py:61-63), padding = the
+// sentinel index n (the kernels give it weight 0).
 __device__ __forceinline__ void emit_list(const int* __restrict__ rank_of, int i, int n, int k,
                                           int pitch, uint16_t* __restrict__ nbr_row,
                                           int32_t* __restrict__ deg_i) {
@@ -31,7 +32,8 @@ __device__ __forceinline__ void emit_list(const int* __restrict__ rank_of, int i
     const int r = rank_of[j];
     if (r < k && j != i) nbr_row[r - (self_rank < r ? 1 : 0)] = (uint16_t)j;
   }
-  for (int p = nonself + threadIdx.x; p < pitch; p += blockDim.x) nbr_row[p] = (uint16_t)i;
+  if (threadIdx.x == 0) nbr_row[nonself] = (uint16_t)i;
+  for (int p = nonself + 1 + threadIdx.x; p < pitch; p += blockDim.x) nbr_row[p] = (uint16_t)n;  // sentinel
   if (threadIdx.x == 0) *deg_i = nonself + 1;
 }
 

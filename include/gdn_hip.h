@@ -49,7 +49,7 @@ int gdn_nbr_pitch(int k);
  *   topk_idx[n,k]  int64, descending cosine, ties -> lower index, NaN ranks highest
  *                  (= model.learned_graph);
  *   nbr[n,pitch]   u16: the top-k entries != i in rank order, then i itself, then
- *                  padding (= i); pitch = gdn_nbr_pitch(k);
+ *                  padding = the sentinel index n; pitch = gdn_nbr_pitch(k);
  *   deg[n]         int32: number of valid entries (k, or k+1 when i is not in its own
  *                  top-k);
  *   cos_out[n,n]   optional (may be NULL) cosine matrix for inspection.               */
