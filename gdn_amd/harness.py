@@ -214,7 +214,7 @@ class SeriesEvaluator:
     are captured once in a HIP graph and replayed."""
 
     def __init__(self, model, x_all: torch.Tensor, y_all: torch.Tensor, batch: int, use_graph: bool = True,
-                 want_scores: bool = False):
+                 want_scores: bool = False, streams: int = 4):
         assert x_all.is_cuda and y_all.is_cuda
         self.model, self.x, self.y, self.batch = model.eval(), x_all, y_all, batch
         self.t, self.n = y_all.shape
@@ -225,13 +225,32 @@ class SeriesEvaluator:
         self.anomaly = torch.empty((self.t,), dtype=torch.float64, device=dev)
         self.scores = torch.empty((self.n, self.t), dtype=torch.float64, device=dev) if want_scores else None
         self.graph = None
+        self.fgraph = None
         self.use_graph = use_graph
+        # independent batches are launched round-robin on side streams (fork/join around the
+        # forward), so launches of a few hundred windows overlap and fill the chip
+        n_launch = (self.t + batch - 1) // batch
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(min(streams, n_launch))] if streams > 1 else []
 
     def _launch_forward(self):
         m = self.model
-        for s in range(0, self.t, self.batch):
-            e = min(self.t, s + self.batch)
-            m.forward_into(self.x[s:e], self.pred[s:e])
+        spans = [(s, min(self.t, s + self.batch)) for s in range(0, self.t, self.batch)]
+        if len(self.side) < 2:
+            for s, e in spans:
+                m.forward_into(self.x[s:e], self.pred[s:e])
+            return
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for st in self.side:
+            st.wait_event(fork)
+        for i, (s, e) in enumerate(spans):
+            with torch.cuda.stream(self.side[i % len(self.side)]):
+                m.forward_into(self.x[s:e], self.pred[s:e])
+        for st in self.side:
+            join = torch.cuda.Event()
+            join.record(st)
+            main.wait_event(join)
 
     def _launch_score(self):
         from . import _lib
@@ -246,17 +265,30 @@ class SeriesEvaluator:
         self._launch_forward()
         self._launch_score()
 
+    def _capture(self, fn):
+        self.model._constants()                      # build graph/constants outside the capture
+        fn()                                         # warm-up (occupancy queries, attributes)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    def forward_only(self):
+        """Forward launches only (multi-GPU: scoring then goes through distributed_anomaly)."""
+        if not self.use_graph:
+            self._launch_forward()
+            return self.pred
+        if self.fgraph is None:
+            self.fgraph = self._capture(self._launch_forward)
+        self.fgraph.replay()
+        return self.pred
+
     def step(self):
         if not self.use_graph:
             self._launch_all()
             return self.anomaly
         if self.graph is None:
-            self.model._constants()                      # build graph/constants outside the capture
-            self._launch_all()                           # warm-up (occupancy queries, attributes)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch_all()
-            self.graph = g
+            self.graph = self._capture(self._launch_all)
         self.graph.replay()
         return self.anomaly
