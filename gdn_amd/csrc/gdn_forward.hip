@@ -18,6 +18,8 @@
 // order of the sum differs per lane, the set does not.
 #include "gdn_common.hpp"
 
+#include <stdlib.h>
+
 #ifndef GDN_GATHER_CHUNK
 #define GDN_GATHER_CHUNK 8
 #endif
@@ -68,6 +70,8 @@ struct Plan {
   int xrows;     // rows of x staged per chunk (project / fused)
   int nbr_lds;   // 1: neighbour lists in LDS, 0: read through L2
   int wl_lds;    // 1: lin.weight staged (permuted) in LDS, 0: lane blocks loaded from global
+  int mfma;      // 1: projection on v_mfma_f32_32x32x2_f32 (x tile at odd pitch xp = wpm + 1)
+  int wpm, xp;   // MFMA path: padded window (16 / 32) and x-tile pitch in floats
   int off_xl, off_si, off_sj, off_deg, off_wl, off_nbr, off_xs;  // float offsets
   int lds_bytes;
 };
@@ -384,13 +388,130 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
   }
 }
 
-// neighbour-list length class: <=2 rounds (k <= 31) and <=5 rounds (k <= 79) keep logits in
-// registers; longer lists take the recompute path.
-template <int D, int MODE>
-__device__ __forceinline__ void aggregate_dispatch(const Plan& pl, const Args& a, float* smem, int b) {
-  if (pl.pitch <= 32) aggregate_window<D, MODE, 2>(pl, a, smem, b);
-  else if (pl.pitch <= 80) aggregate_window<D, MODE, 5>(pl, a, smem, b);
-  else aggregate_window<D, MODE, 0>(pl, a, smem, b);
+// neighbour-list length class (kernel template parameter MAXR): 2 rounds (k <= 31) and 5 rounds
+// (k <= 79) keep the logits in registers; 0 = any length, logits recomputed per pass.
+// ------------------------------------------------------------------ projection on the matrix cores
+// xlin[32-row block, 32-col block] = sum_k x[row, k] * lin[col, k] with v_mfma_f32_32x32x2_f32
+// (exact fp32, one k-pair per instruction).  A operand: lane l holds x[row = l&31][k = 2kk + (l>>5)]
+// (x tile at the odd pitch xp -> conflict-free ds_read_b32); B operand: lin[col = l&31][k], kept in
+// registers for the whole workgroup; C/D: reg r of lane l = xlin[(r&3) + 8(r>>2) + 4(l>>5)][l&31].
+// One wave per 32-row block.  The attention scalars s_i/s_j are one thread per sensor.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int XU>
+struct XFlat {
+  float v[XU];
+};
+
+template <int XU>
+__device__ __forceinline__ void xflat_load(const float* xg, int cnt, XFlat<XU>& r) {
+#pragma unroll
+  for (int u = 0; u < XU; ++u)   // unconditional, clamped: stays in registers
+    r.v[u] = xg[min((int)threadIdx.x + u * (int)blockDim.x, cnt - 1)];
+}
+
+template <int XU>
+__device__ __forceinline__ void xflat_store(float* xs, int cnt, int w, float inv_w, int xp,
+                                            const XFlat<XU>& r) {
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int t = threadIdx.x + u * blockDim.x;
+    if (t < cnt) {
+      const int row = (int)((t + 0.5f) * inv_w);   // exact for t < 2^16, w <= 64
+      xs[row * xp + (t - row * w)] = r.v[u];
+    }
+  }
+}
+
+template <int D, int MODE, int WPM>
+__device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, float* smem, int b,
+                                             const float (&wb)[D / 32][WPM / 2]) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const float* xs = smem + pl.off_xs;
+  float* xl = smem + pl.off_xl;
+  float* si = smem + pl.off_si;
+  float* sj = smem + pl.off_sj;
+  constexpr int XP = WPM + 1;
+  // attention scalars: s = x_row . a + c[sensor]
+  for (int t = tid; t < pl.n; t += nth) {
+    float pi = a.node_terms[2 * GDN_A_PITCH + t];
+    float pj = a.node_terms[2 * GDN_A_PITCH + pl.n + t];
+    const float* xr = xs + t * XP;
+#pragma unroll
+    for (int k = 0; k < WPM; ++k) {
+      const float xv = xr[k];
+      pi = fmaf(xv, a.node_terms[k], pi);
+      pj = fmaf(xv, a.node_terms[GDN_A_PITCH + k], pj);
+    }
+    si[t] = pi;
+    sj[t] = pj;
+    if constexpr (MODE == MODE_PROJECT) {
+      a.si_out[(size_t)b * pl.n + t] = pi;
+      a.sj_out[(size_t)b * pl.n + t] = pj;
+    }
+  }
+  const int nrb = (pl.n + 31) >> 5;
+  for (int rb = wv; rb < nrb; rb += nw) {
+    const float* arow = xs + min(rb * 32 + l32, pl.n - 1) * XP + h;
+    float av[WPM / 2];
+#pragma unroll
+    for (int kk = 0; kk < WPM / 2; ++kk) av[kk] = arow[2 * kk];
+#pragma unroll
+    for (int cb = 0; cb < D / 32; ++cb) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < WPM / 2; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], wb[cb][kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < pl.n) {
+          xl[row * D + cb * 32 + l32] = acc[r];
+          if constexpr (MODE == MODE_PROJECT)
+            a.xlin_out[((size_t)b * pl.n + row) * D + cb * 32 + l32] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+template <int D, int MODE, int WPM, int XU, int MAXR>
+__device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, float* smem) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int l32 = tid & 31, h = (tid >> 5) & 1;
+  constexpr int XP = WPM + 1;
+  float* xs = smem + pl.off_xs;
+  // zero the x tile once: pad columns w..WPM-1 are never written again
+  for (int t = tid; t < pl.n * XP; t += nth) xs[t] = 0.f;
+  float wb[D / 32][WPM / 2];
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int kk = 0; kk < WPM / 2; ++kk) {
+      const int k = 2 * kk + h;
+      wb[cb][kk] = k < pl.w ? a.lin_w[(size_t)(cb * 32 + l32) * pl.w + k] : 0.f;
+    }
+  const int cnt = pl.n * pl.w;
+  const float inv_w = 1.0f / (float)pl.w;
+  XFlat<XU> xr;
+  xflat_load<XU>(a.x + (size_t)blockIdx.x * cnt, cnt, xr);
+  __syncthreads();   // zero fill done before the first store
+  for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
+    xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
+    __syncthreads();
+    const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round: harmless re-read
+    xflat_load<XU>(a.x + (size_t)nb * cnt, cnt, xr);        // lands under the math
+    project_mfma<D, MODE, WPM>(pl, a, smem, b, wb);
+    __syncthreads();
+    if constexpr (MODE == MODE_FUSED) {
+      aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
+      __syncthreads();
+    }
+  }
 }
 
 // ------------------------------------------------------------------ the kernel
@@ -436,9 +557,13 @@ __device__ __forceinline__ void stage_x(const Plan& pl, const float* xg, float* 
   }
 }
 
-template <int D, int WCH, int MODE, int NT>
+// PROJ selects the projection variant at COMPILE time (a runtime branch would make every variant
+// pay the registers of the hungriest one): 0 VALU w<=8, 1 VALU w-chunks of 16,
+// 2 MFMA w<=16 (<=8 x values per thread), 3 MFMA w<=16 (<=16 per thread), 4 MFMA w<=32.
+template <int D, int MODE, int NT, int PROJ, int MAXR>
 __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Args a) {
   using G = Geo<D>;
+  constexpr int WCH = PROJ == 0 ? 8 : 16;
   extern __shared__ float4 smem_f4[];
   float* smem = reinterpret_cast<float*>(smem_f4);
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -501,7 +626,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           psi = a.si_in[(size_t)nb * pl.n + tn];
           psj = a.sj_in[(size_t)nb * pl.n + tn];
         }
-        aggregate_dispatch<D, MODE>(pl, a, smem, b);
+        aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
         __syncthreads();  // the tile is overwritten by the next window
       }
 #undef GDN_PRE_ALL
@@ -516,11 +641,16 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           sj[t] = a.sj_in[(size_t)b * pl.n + t];
         }
         __syncthreads();
-        aggregate_dispatch<D, MODE>(pl, a, smem, b);
+        aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
         __syncthreads();
       }
     }
   } else {
+    if constexpr (PROJ >= 2) {
+      static_assert(D >= 32 || PROJ < 2, "MFMA projection needs d >= 32");
+      window_loop_mfma<D, MODE, (PROJ == 4 ? 32 : 16), (PROJ == 2 ? 8 : 16), MAXR>(pl, a, smem);
+      return;
+    }
     float* xs = smem + pl.off_xs;
     float* wlds = smem + pl.off_wl;
     const int nch = pl.wp / WCH;
@@ -542,7 +672,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
         }
         __syncthreads();
         if constexpr (MODE == MODE_FUSED) {
-          aggregate_dispatch<D, MODE>(pl, a, smem, b);
+          aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
           __syncthreads();
         }
       }
@@ -562,7 +692,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           __syncthreads();
         }
         if constexpr (MODE == MODE_FUSED) {
-          aggregate_dispatch<D, MODE>(pl, a, smem, b);
+          aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
           __syncthreads();
         }
       }
@@ -633,20 +763,36 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   pl->off_sj = off; off += npad;
   pl->off_deg = off; off += (npad / 2 + 3) & ~3;
   pl->off_wl = off;
-  pl->wl_lds = 0;
-  if (mode != MODE_ATTN && (off + d * pl->wp) * 4 + 16 * pl->wp * 4 + 2048 <= LDS_MAX / 2) {
+  pl->wl_lds = 0; pl->mfma = 0; pl->wpm = 0; pl->xp = 0;
+  const int nbr_bytes = n * pl->pitch * 2;
+  const int base_bytes = off * 4;
+  if (base_bytes > LDS_MAX) return GDN_ERR_UNSUPPORTED;
+  // threads: small tiles run 256-thread workgroups (several per CU), big tiles own the CU
+  const int est = base_bytes + (mode != MODE_PROJECT ? nbr_bytes : 0) + n * (pl->wp + 1) * 4;
+  *threads = est > 80 * 1024 ? 512 : 256;
+  // projection on the matrix cores: d >= 32, w <= 32, whole window staged at once
+  if (mode != MODE_ATTN && d >= 32 && w <= 32 && !getenv("GDN_NO_MFMA")) {
+    const int wpm = w <= 16 ? 16 : 32;
+    const int xs_bytes = n * (wpm + 1) * 4;
+    const int need = base_bytes + xs_bytes;
+    if (need <= LDS_MAX && n * w <= 16 * *threads) {
+      pl->mfma = 1; pl->wpm = wpm; pl->xp = wpm + 1;
+    }
+  }
+  if (!pl->mfma && mode != MODE_ATTN &&
+      (off + d * pl->wp) * 4 + 16 * pl->wp * 4 + 2048 <= LDS_MAX / 2) {
     pl->wl_lds = 1;                               // small tiles: keep the weights beside them
     off += d * pl->wp;
   }
   pl->off_nbr = off;
   pl->off_xs = off;
   int fixed = off * 4;
-  const int nbr_bytes = n * pl->pitch * 2;
-  const int xs_full = n * pl->wp * 4;
+  const int xs_full = pl->mfma ? n * pl->xp * 4 : n * pl->wp * 4;
   if (fixed > LDS_MAX) return GDN_ERR_UNSUPPORTED;
-  // neighbour lists go to LDS when they fit beside a useful x chunk
+  // neighbour lists go to LDS when they fit beside the x tile (MFMA path: the whole window)
   int remaining = LDS_MAX - fixed;
-  if (mode != MODE_PROJECT && nbr_bytes <= remaining - (mode == MODE_FUSED ? 16 * pl->wp * 4 : 0)) {
+  const int xs_min = mode == MODE_ATTN ? 0 : (pl->mfma ? xs_full : (mode == MODE_FUSED ? 16 * pl->wp * 4 : 0));
+  if (mode != MODE_PROJECT && nbr_bytes <= remaining - xs_min) {
     pl->nbr_lds = 1;
     pl->off_xs = pl->off_nbr + nbr_bytes / 4;
     remaining -= nbr_bytes;
@@ -654,22 +800,21 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   if (mode != MODE_ATTN) {
     if (xs_full <= remaining) {
       pl->xrows = n;
+      remaining -= xs_full;
     } else {
       pl->xrows = (remaining / (pl->wp * 4)) & ~15;
       if (pl->xrows < 16) return GDN_ERR_UNSUPPORTED;
+      remaining -= pl->xrows * pl->wp * 4;
     }
-    remaining -= pl->xrows * pl->wp * 4;
   }
   pl->lds_bytes = LDS_MAX - remaining;
-  // small windows: 256 threads and several workgroups per CU; big tiles own the CU -> 1024 threads
-  *threads = pl->lds_bytes > 80 * 1024 ? 512 : 256;
   return GDN_OK;
 }
 
-template <int D, int WCH, int MODE, int NT>
+template <int D, int MODE, int NT, int PROJ, int MAXR>
 int launch_window(const Plan& pl, const Args& a, hipStream_t stream) {
   constexpr int threads = NT;
-  auto kern = gdn_window_kernel<D, WCH, MODE, NT>;
+  auto kern = gdn_window_kernel<D, MODE, NT, PROJ, MAXR>;
   static bool attr_set = false;
   static int occ_cache_lds = -1, occ = 0;
   if (!attr_set) {
@@ -692,16 +837,41 @@ int launch_window(const Plan& pl, const Args& a, hipStream_t stream) {
   return gdn_launch_status();
 }
 
+// runtime -> compile-time selection, one level per parameter
+template <int D, int MODE, int NT, int PROJ>
+int select_maxr(const Plan& pl, const Args& a, hipStream_t st) {
+  if constexpr (MODE == MODE_PROJECT) {
+    return launch_window<D, MODE, NT, PROJ, 0>(pl, a, st);
+  } else {
+    if (pl.pitch <= 32) return launch_window<D, MODE, NT, PROJ, 2>(pl, a, st);
+    if (pl.pitch <= 80) return launch_window<D, MODE, NT, PROJ, 5>(pl, a, st);
+    return launch_window<D, MODE, NT, PROJ, 0>(pl, a, st);
+  }
+}
+
+template <int D, int MODE, int NT>
+int select_proj(const Plan& pl, const Args& a, int threads, hipStream_t st) {
+  if constexpr (MODE == MODE_ATTN) {
+    return select_maxr<D, MODE, NT, 1>(pl, a, st);
+  } else {
+    if constexpr (D >= 32) {
+      if (pl.mfma) {
+        if (pl.wpm == 32) return select_maxr<D, MODE, NT, 4>(pl, a, st);
+        if (pl.n * pl.w <= 8 * threads) return select_maxr<D, MODE, NT, 2>(pl, a, st);
+        return select_maxr<D, MODE, NT, 3>(pl, a, st);
+      }
+    }
+    if (pl.wp == 8) return select_maxr<D, MODE, NT, 0>(pl, a, st);
+    return select_maxr<D, MODE, NT, 1>(pl, a, st);
+  }
+}
+
 template <int MODE>
 int dispatch_window(const Plan& pl, const Args& a, int threads, hipStream_t stream) {
-#define GDN_CASE(DD)                                                                  \
-  case DD:                                                                            \
-    if (threads == 256) {                                                             \
-      if (MODE == MODE_ATTN || pl.wp != 8) return launch_window<DD, 16, MODE, 256>(pl, a, stream); \
-      return launch_window<DD, 8, MODE, 256>(pl, a, stream);                          \
-    }                                                                                 \
-    if (MODE == MODE_ATTN || pl.wp != 8) return launch_window<DD, 16, MODE, 512>(pl, a, stream);  \
-    return launch_window<DD, 8, MODE, 512>(pl, a, stream);
+#define GDN_CASE(DD)                                                              \
+  case DD:                                                                        \
+    if (threads == 256) return select_proj<DD, MODE, 256>(pl, a, threads, stream); \
+    return select_proj<DD, MODE, 512>(pl, a, threads, stream);
   switch (pl.d) {
     GDN_CASE(16)
     GDN_CASE(32)

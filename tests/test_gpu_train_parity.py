@@ -37,8 +37,10 @@ def test_train_step_matches_reference_grads(case, gpu_device):
     out = model(x, None)
     loss = torch.nn.functional.mse_loss(out, y, reduction="mean")       # train.py:20-23
     loss.backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), data["train_out"], atol=2e-5, rtol=0)
-    np.testing.assert_allclose(loss.item(), float(data["train_loss"]), atol=2e-5, rtol=0)
+    # train-mode BatchNorm normalises by the statistics of as few as B*N = 50..254 rows, which
+    # amplifies fp32 association differences ~1/sigma: 5e-5 here (north_star bar: 1e-4)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), data["train_out"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(loss.item(), float(data["train_loss"]), atol=5e-5, rtol=0)
     for name, prm in model.named_parameters():
         assert prm.grad is not None, name
         np.testing.assert_allclose(prm.grad.cpu().numpy(), data["g/" + name], atol=5e-5, rtol=1e-3,
