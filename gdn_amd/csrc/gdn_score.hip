@@ -39,6 +39,14 @@ __global__ __launch_bounds__(256) void score_delta_kernel(const float* __restric
 // One workgroup per sensor: MSB-first radix select (8-bit digits) of NQ ranks at once over the
 // sensor's t keys (non-negative doubles order like their bit patterns).  Ranks whose prefixes
 // still coincide share one histogram.
+//  * KPT > 0: every thread keeps KPT keys in registers for all 8 passes (t <= KPT * blockDim) plus
+//    an ALIVE bit per key: a key that matches no rank's prefix can never match again, so after
+//    the first two or three digits almost every wave skips its keys and the late passes are free;
+//    KPT == 0: keys are re-read from memory each pass (any t).
+//  * a whole wave landing in one bin (the exponent bytes) does one add of 64;
+//  * the bin holding each rank is found by one wave per rank with a shuffle scan (not a serial
+//    walk over 256 LDS words).
+template <int KPT>
 __global__ __launch_bounds__(1024) void score_select_kernel(const double* __restrict__ ws, int t,
                                                             const SelectArgs sa, double* __restrict__ med_iqr) {
   __shared__ unsigned int hist[NQ][256];
@@ -48,6 +56,18 @@ __global__ __launch_bounds__(1024) void score_select_kernel(const double* __rest
   const int s = blockIdx.x;
   const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(ws) + (size_t)s * t;
   const int tid = threadIdx.x, nth = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  constexpr int NK = KPT > 0 ? KPT : 1;
+  unsigned long long kreg[NK];
+  unsigned int alive = 0u;
+  if constexpr (KPT > 0) {
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+      const int i = tid + u * nth;
+      kreg[u] = keys[min(i, t - 1)];                          // unconditional, clamped
+      if (i < t) alive |= 1u << u;
+    }
+  }
   if (tid < NQ) {
     prefix[tid] = 0ull;
     rem[tid] = sa.rank[tid];
@@ -70,28 +90,76 @@ __global__ __launch_bounds__(1024) void score_select_kernel(const double* __rest
       pf[q] = prefix[q];
       active[q] = rep[q] == q;
     }
-    for (int i = tid; i < t; i += nth) {
-      const unsigned long long key = keys[i];
+    // returns whether the key still matches some rank's prefix
+    auto tally = [&](unsigned long long key, bool live) -> bool {
       const unsigned int digit = (unsigned int)(key >> shift) & 255u;
+      const unsigned int d0 = __builtin_amdgcn_readfirstlane(digit);
+      bool any = false;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
+        if (!active[q]) continue;   // uniform
         // high bits above this digit must equal the prefix (pass 0: no high bits)
-        const bool match = pass == 0 ? true : ((key ^ pf[q]) >> (shift + 8)) == 0ull;
-        if (active[q] && match) atomicAdd(&hist[q][digit], 1u);
+        const bool match = live && (pass == 0 ? true : ((key ^ pf[q]) >> (shift + 8)) == 0ull);
+        any |= match;
+        if (__all(match && digit == d0)) {
+          if (lane == 0) atomicAdd(&hist[q][d0], 64u);   // whole wave in one bin: one add of 64
+        } else if (match) {
+          atomicAdd(&hist[q][digit], 1u);
+        }
+      }
+      return any;
+    };
+    if constexpr (KPT > 0) {
+#pragma unroll
+      for (int u = 0; u < KPT; ++u) {
+        const bool live = (alive >> u) & 1u;
+        if (__any(live)) {                       // wave-uniform skip of dead keys
+          if (!tally(kreg[u], live)) alive &= ~(1u << u);
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < t; i0 += 4 * nth) {
+        unsigned long long k4[4];
+        bool l4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + tid + u * nth;
+          k4[u] = keys[min(i, t - 1)];
+          l4[u] = i < t;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tally(k4[u], l4[u]);
       }
     }
     __syncthreads();
-    if (tid < NQ) {
-      const unsigned int* h = hist[rep[tid]];
-      int left = rem[tid];
-      int b = 0;
-      for (; b < 255; ++b) {
-        const int c = (int)h[b];
-        if (left < c) break;
-        left -= c;
+    // wave q locates rank q's bin: lane l owns bins 4l..4l+3, inclusive scan over lanes
+    if (wv < NQ) {
+      const unsigned int* h = hist[rep[wv]];
+      const uint4 c4 = *reinterpret_cast<const uint4*>(h + 4 * lane);
+      const int mine = (int)(c4.x + c4.y + c4.z + c4.w);
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
       }
-      prefix[tid] |= (unsigned long long)b << shift;
-      rem[tid] = left;
+      const int left0 = rem[wv];
+      const int excl = incl - mine;
+      // the owning lane is the first whose inclusive count exceeds the remaining rank
+      const bool owner = left0 >= excl && left0 < incl;
+      if (owner) {
+        int left = left0 - excl, bin = 4 * lane;
+        const int c[4] = {(int)c4.x, (int)c4.y, (int)c4.z, (int)c4.w};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (left >= c[j] && bin == 4 * lane + j) {
+            left -= c[j];
+            bin += 1;
+          }
+        }
+        prefix[wv] |= (unsigned long long)bin << shift;
+        rem[wv] = left;
+      }
     }
     __syncthreads();
   }
@@ -181,7 +249,12 @@ extern "C" int gdn_score_quantiles(const float* pred, const float* gt, int t, in
     sa.rank[3 + 2 * h] = ihi;
     sa.gamma[h] = vi - lo;
   }
-  hipLaunchKernelGGL(score_select_kernel, dim3(n), dim3(1024), 0, st, workspace, t, sa, med_iqr);
+  if (t <= 8 * 1024)
+    hipLaunchKernelGGL(score_select_kernel<8>, dim3(n), dim3(1024), 0, st, workspace, t, sa, med_iqr);
+  else if (t <= 32 * 1024)
+    hipLaunchKernelGGL(score_select_kernel<32>, dim3(n), dim3(1024), 0, st, workspace, t, sa, med_iqr);
+  else
+    hipLaunchKernelGGL(score_select_kernel<0>, dim3(n), dim3(1024), 0, st, workspace, t, sa, med_iqr);
   return gdn_launch_status();
 }
 

@@ -26,7 +26,7 @@ def test_scores_match_reference_evaluate(case, gpu_device):
     np.testing.assert_allclose(one, data["scores"][0], rtol=1e-12, atol=1e-13)
 
 
-@pytest.mark.parametrize("t,n", [(32768, 127), (4097, 51), (4, 3), (3, 2), (1, 1)])
+@pytest.mark.parametrize("t,n", [(32768, 127), (40001, 5), (8192, 9), (4097, 51), (4, 3), (3, 2), (1, 1)])
 def test_scores_full_size_against_oracle(t, n, gpu_device):
     from gdn_amd import evaluate
     g = torch.Generator().manual_seed(t + n)
