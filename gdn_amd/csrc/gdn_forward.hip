@@ -21,7 +21,10 @@
 #include <stdlib.h>
 
 #ifndef GDN_GATHER_CHUNK
-#define GDN_GATHER_CHUNK 8
+#define GDN_GATHER_CHUNK 8        // fused kernel: row fetches in flight per wave
+#endif
+#ifndef GDN_GATHER_CHUNK_ATTN
+#define GDN_GATHER_CHUNK_ATTN 4   // K8 kernel also holds the next tile's 32 prefetch registers
 #endif
 
 namespace {
@@ -30,6 +33,27 @@ template <int V>
 struct Pack {
   float v[V];
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += a * src over V columns, as v_pk_fma_f32 on column pairs (the SLP vectoriser does not
+// pack this loop reliably; scalar v_fmac doubles the instruction count of the gather)
+template <int V>
+__device__ __forceinline__ void axpy_pack(float a, const Pack<V>& src, Pack<V>& acc) {
+  if constexpr (V >= 2) {
+    const f32x2 a2 = {a, a};
+#pragma unroll
+    for (int v = 0; v < V; v += 2) {
+      f32x2 s2 = {src.v[v], src.v[v + 1]};
+      f32x2 c2 = {acc.v[v], acc.v[v + 1]};
+      c2 = __builtin_elementwise_fma(a2, s2, c2);
+      acc.v[v] = c2[0];
+      acc.v[v + 1] = c2[1];
+    }
+  } else {
+    acc.v[0] = fmaf(a, src.v[0], acc.v[0]);
+  }
+}
 
 template <int V>
 __device__ __forceinline__ Pack<V> ld_pack(const float* p) {
@@ -224,7 +248,7 @@ __device__ __forceinline__ void project_chunk(const Plan& pl, const Args& a, flo
 // acc += alpha_q * xlin[j_q] for the 16 neighbours q held by the lanes of this row.  Step S uses
 // the pair rotated by S lanes; every rotation is taken from the ORIGINAL registers (row_ror:S), so
 // the 16 LDS addresses are independent and all 16 ds_read_b128 can be in flight at once.
-template <int D, int S>
+template <int D, int S, int CH>
 __device__ __forceinline__ void gather_steps(const char* xl_lane, float al, int jb,
                                              Pack<Geo<D>::VEC>& acc) {
   using G = Geo<D>;
@@ -239,11 +263,10 @@ __device__ __forceinline__ void gather_steps(const char* xl_lane, float al, int 
       j_s = dpp_i<0x120 + S>(jb);
     }
     const Pack<G::VEC> src = ld_pack<G::VEC>(reinterpret_cast<const float*>(xl_lane + j_s));
-#pragma unroll
-    for (int v = 0; v < G::VEC; ++v) acc.v[v] = fmaf(a_s, src.v[v], acc.v[v]);
-    // keep at most GDN_GATHER_CHUNK row fetches in flight: bounds the VGPRs the scheduler may spend
-    if constexpr ((S + 1) % GDN_GATHER_CHUNK == 0 && S + 1 < 16) __builtin_amdgcn_sched_barrier(0);
-    gather_steps<D, S + 1>(xl_lane, al, jb, acc);
+    axpy_pack<G::VEC>(a_s, src, acc);
+    // keep at most CH row fetches in flight: bounds the VGPRs the scheduler may spend
+    if constexpr ((S + 1) % CH == 0 && S + 1 < 16) __builtin_amdgcn_sched_barrier(0);
+    gather_steps<D, S + 1, CH>(xl_lane, al, jb, acc);
   }
 }
 
@@ -251,21 +274,31 @@ struct AggCtx {
   const float* si;
   const float* sj;
   const uint16_t* degs;
-  const uint16_t* nbr;
+  const uint16_t* nbr_lds;   // LDS copy of the neighbour lists, or null
+  const uint16_t* nbr_glb;   // the lists in global memory (used when they do not fit in LDS)
   const char* xl_lane;
 };
 
-// Softmax weights + weighted neighbour sum of ONE target row.  MAXR > 0: the target has at most
-// MAXR rounds of 16 neighbours and logits stay in registers; MAXR == 0: any length, logits are
-// recomputed per pass.  Returns the aggregate (without bias) in `acc`.
-template <int D, int MODE, int MAXR>
+// one list entry; where the lists live is a COMPILE-TIME property of the kernel variant (a pointer
+// selected at run time would degrade every access to a FLAT load)
+template <bool IN_LDS>
+__device__ __forceinline__ int nbr_entry(const AggCtx& c, int idx) {
+  if constexpr (IN_LDS) return (int)c.nbr_lds[idx];
+  else return (int)c.nbr_glb[idx];
+}
+
+// Softmax weights + weighted neighbour sum of ONE target row.
+//   MAXR = 1, 2 : the list pitch is exactly 16*MAXR; every round runs unconditionally (padding
+//                 slots hold the sentinel, weight 0), logits in registers, straight-line code;
+//   MAXR = 5    : up to 5 rounds (wave-uniform skip of the unused ones), logits in registers;
+//   MAXR = 0    : any length, logits recomputed per pass.
+// Returns the aggregate (without bias) in `acc`.
+template <int D, int MODE, int MAXR, bool NL>
 __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, const AggCtx& c, int b, int i,
                                                  int slice, int l16, Pack<Geo<D>::VEC>& acc) {
   using G = Geo<D>;
-  const int degi = c.degs[i];
-  const int rounds = (degi + 15) >> 4;
   const float sti = c.si[i];
-  const uint16_t* nrow = c.nbr + (size_t)i * pl.pitch;
+  const int row0 = i * pl.pitch;
   float* arow = nullptr;
   if constexpr (MODE == MODE_ATTN) {
     if (a.alpha && slice == 0) arow = a.alpha + ((size_t)b * pl.n + i) * pl.pitch;
@@ -274,16 +307,15 @@ __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, 
   for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
 
   if constexpr (MAXR > 0) {
-    // padding slots hold the sentinel index n: sj[n] = -inf (weight 0) and tile row n = 0, so no
-    // per-lane validity test is needed
+    const int nr = MAXR <= 2 ? MAXR : (pl.pitch >> 4);   // rounds in use (wave-uniform)
     int jn[MAXR];
     float e[MAXR];
     float m = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) jn[r] = r < rounds ? (int)nrow[r * 16 + l16] : pl.n;
+    for (int r = 0; r < MAXR; ++r) jn[r] = r < nr ? nbr_entry<NL>(c, row0 + r * 16 + l16) : pl.n;
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
-      e[r] = leaky(sti + c.sj[jn[r]]);
+      e[r] = leaky(sti + c.sj[jn[r]]);   // sentinel: s_j[n] = -inf
       m = fmaxf(m, e[r]);
     }
     m = row16_max(m);
@@ -297,46 +329,46 @@ __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, 
     const float inv = __builtin_amdgcn_rcpf(sum + GDN_SOFTMAX_EPS);
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
-      if (r < rounds) {
+      if (MAXR <= 2 || r < nr) {
         const float al = e[r] * inv;
         if constexpr (MODE == MODE_ATTN) {
           if (arow) arow[r * 16 + l16] = al;
         }
-        gather_steps<D, 0>(c.xl_lane, al, jn[r] * (D * 4), acc);
+        gather_steps<D, 0, (MODE == MODE_ATTN ? GDN_GATHER_CHUNK_ATTN : GDN_GATHER_CHUNK)>(c.xl_lane, al, jn[r] * (D * 4), acc);
       }
     }
   } else {
+    const int rounds = (c.degs[i] + 15) >> 4;
     float m = -INFINITY;
-    for (int r = 0; r < rounds; ++r) {
-      const int p = r * 16 + l16;
-      m = fmaxf(m, leaky(sti + c.sj[nrow[p]]));
-    }
+    for (int r = 0; r < rounds; ++r)
+      m = fmaxf(m, leaky(sti + c.sj[nbr_entry<NL>(c, row0 + r * 16 + l16)]));
     m = row16_max(m);
     float sum = 0.f;
-    for (int r = 0; r < rounds; ++r) {
-      const int p = r * 16 + l16;
-      sum += __expf(leaky(sti + c.sj[nrow[p]]) - m);
-    }
+    for (int r = 0; r < rounds; ++r)
+      sum += __expf(leaky(sti + c.sj[nbr_entry<NL>(c, row0 + r * 16 + l16)]) - m);
     sum = row16_sum(sum);
     const float inv = __builtin_amdgcn_rcpf(sum + GDN_SOFTMAX_EPS);
     for (int r = 0; r < rounds; ++r) {
       const int p = r * 16 + l16;
-      const int j = nrow[p];
+      const int j = nbr_entry<NL>(c, row0 + p);
       const float al = __expf(leaky(sti + c.sj[j]) - m) * inv;
       if constexpr (MODE == MODE_ATTN) {
         if (arow) arow[p] = al;
       }
-      gather_steps<D, 0>(c.xl_lane, al, j * (D * 4), acc);
+      gather_steps<D, 0, (MODE == MODE_ATTN ? GDN_GATHER_CHUNK_ATTN : GDN_GATHER_CHUNK)>(c.xl_lane, al, j * (D * 4), acc);
     }
-  }
-  if constexpr (MODE == MODE_ATTN) {
-    // zero the alpha slots of rounds this target does not use
-    if (arow)
-      for (int p = rounds * 16 + l16; p < pl.pitch; p += 16) arow[p] = 0.f;
+    if constexpr (MODE == MODE_ATTN) {
+      // zero the alpha slots of rounds this target does not use
+      if (arow)
+        for (int p = rounds * 16 + l16; p < pl.pitch; p += 16) arow[p] = 0.f;
+    }
   }
 }
 
-template <int D, int MODE, int MAXR>
+// LST encodes the neighbour-list variant of the kernel: 1, 2, 5 = lists in LDS with exactly 1 / exactly
+// 2 / up to 5 rounds of 16 (logits in registers); 6 = up to 5 rounds, lists read from global (they do
+// not fit beside a big tile); 0 = any length, lists in global, logits recomputed per pass.
+template <int D, int MODE, int LST>
 __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, float* smem, int b) {
   using G = Geo<D>;
   const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
@@ -347,7 +379,8 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
   c.si = smem + pl.off_si;
   c.sj = smem + pl.off_sj;
   c.degs = reinterpret_cast<const uint16_t*>(smem + pl.off_deg);
-  c.nbr = pl.nbr_lds ? reinterpret_cast<const uint16_t*>(smem + pl.off_nbr) : a.nbr;
+  c.nbr_lds = reinterpret_cast<const uint16_t*>(smem + pl.off_nbr);
+  c.nbr_glb = a.nbr;
   c.xl_lane = reinterpret_cast<const char*>(smem + pl.off_xl + d0);
 
   // per-lane constants of the epilogue
@@ -367,7 +400,7 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
     Pack<G::VEC> emb_i;
     if constexpr (MODE == MODE_FUSED) emb_i = ld_pack<G::VEC>(a.emb + (size_t)i * D + d0);
     Pack<G::VEC> acc;
-    aggregate_target<D, MODE, MAXR>(pl, a, c, b, i, slice, l16, acc);
+    aggregate_target<D, MODE, (LST == 6 ? 5 : LST), (LST >= 1 && LST <= 5)>(pl, a, c, b, i, slice, l16, acc);
 #pragma unroll
     for (int v = 0; v < G::VEC; ++v) acc.v[v] += bias.v[v];
     if constexpr (MODE == MODE_ATTN) {
@@ -388,8 +421,8 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
   }
 }
 
-// neighbour-list length class (kernel template parameter MAXR): 2 rounds (k <= 31) and 5 rounds
-// (k <= 79) keep the logits in registers; 0 = any length, logits recomputed per pass.
+// neighbour-list length class (kernel template parameter MAXR): exactly 1 or 2 rounds of 16
+// (k <= 15 / k <= 31), up to 5 rounds (k <= 79), or 0 = any length (logits recomputed per pass).
 // ------------------------------------------------------------------ projection on the matrix cores
 // xlin[32-row block, 32-col block] = sum_k x[row, k] * lin[col, k] with v_mfma_f32_32x32x2_f32
 // (exact fp32, one k-pair per instruction).  A operand: lane l holds x[row = l&31][k = 2kk + (l>>5)]
@@ -479,7 +512,7 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
   }
 }
 
-template <int D, int MODE, int WPM, int XU, int MAXR>
+template <int D, int MODE, int WPM, int XU, int LST>
 __device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, float* smem) {
   const int tid = threadIdx.x, nth = blockDim.x;
   const int l32 = tid & 31, h = (tid >> 5) & 1;
@@ -500,17 +533,17 @@ __device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, 
   XFlat<XU> xr;
   xflat_load<XU>(a.x + (size_t)blockIdx.x * cnt, cnt, xr);
   __syncthreads();   // zero fill done before the first store
+  xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
+  __syncthreads();
+  // two barriers per window: [loads of b+1 | s + MFMA of b] B [aggregate b | store x of b+1] C
   for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
-    xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
-    __syncthreads();
     const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round: harmless re-read
     xflat_load<XU>(a.x + (size_t)nb * cnt, cnt, xr);        // lands under the math
     project_mfma<D, MODE, WPM>(pl, a, smem, b, wb);
-    __syncthreads();
-    if constexpr (MODE == MODE_FUSED) {
-      aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
-      __syncthreads();
-    }
+    __syncthreads();                                        // B: tile + scalars ready, x tile free
+    if constexpr (MODE == MODE_FUSED) aggregate_window<D, MODE, LST>(pl, a, smem, b);
+    xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
+    __syncthreads();                                        // C: tile free, next x tile visible
   }
 }
 
@@ -560,8 +593,8 @@ __device__ __forceinline__ void stage_x(const Plan& pl, const float* xg, float* 
 // PROJ selects the projection variant at COMPILE time (a runtime branch would make every variant
 // pay the registers of the hungriest one): 0 VALU w<=8, 1 VALU w-chunks of 16,
 // 2 MFMA w<=16 (<=8 x values per thread), 3 MFMA w<=16 (<=16 per thread), 4 MFMA w<=32.
-template <int D, int MODE, int NT, int PROJ, int MAXR>
-__global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Args a) {
+template <int D, int MODE, int NT, int PROJ, int LST>
+__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void gdn_window_kernel(const Plan pl, const Args a) {
   using G = Geo<D>;
   constexpr int WCH = PROJ == 0 ? 8 : 16;
   extern __shared__ float4 smem_f4[];
@@ -575,7 +608,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
     for (int t = tid; t < pl.n; t += nth) degs[t] = (uint16_t)a.deg[t];
     for (int t = tid; t < D; t += nth) smem[pl.off_xl + pl.n * D + t] = 0.f;
     if (tid == 0) smem[pl.off_sj + pl.n] = -INFINITY;
-    if (pl.nbr_lds) {
+    if constexpr (LST >= 1 && LST <= 5) {
       // n*pitch u16 = n*pitch/8 uint4 (pitch is a multiple of 16)
       const uint4* src = reinterpret_cast<const uint4*>(a.nbr);
       uint4* dst = reinterpret_cast<uint4*>(smem + pl.off_nbr);
@@ -626,7 +659,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           psi = a.si_in[(size_t)nb * pl.n + tn];
           psj = a.sj_in[(size_t)nb * pl.n + tn];
         }
-        aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
+        aggregate_window<D, MODE, LST>(pl, a, smem, b);
         __syncthreads();  // the tile is overwritten by the next window
       }
 #undef GDN_PRE_ALL
@@ -641,14 +674,14 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           sj[t] = a.sj_in[(size_t)b * pl.n + t];
         }
         __syncthreads();
-        aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
+        aggregate_window<D, MODE, LST>(pl, a, smem, b);
         __syncthreads();
       }
     }
   } else {
     if constexpr (PROJ >= 2) {
       static_assert(D >= 32 || PROJ < 2, "MFMA projection needs d >= 32");
-      window_loop_mfma<D, MODE, (PROJ == 4 ? 32 : 16), (PROJ == 2 ? 8 : 16), MAXR>(pl, a, smem);
+      window_loop_mfma<D, MODE, (PROJ == 4 ? 32 : 16), (PROJ == 2 ? 8 : 16), LST>(pl, a, smem);
       return;
     }
     float* xs = smem + pl.off_xs;
@@ -672,7 +705,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
         }
         __syncthreads();
         if constexpr (MODE == MODE_FUSED) {
-          aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
+          aggregate_window<D, MODE, LST>(pl, a, smem, b);
           __syncthreads();
         }
       }
@@ -692,7 +725,7 @@ __global__ __launch_bounds__(NT) void gdn_window_kernel(const Plan pl, const Arg
           __syncthreads();
         }
         if constexpr (MODE == MODE_FUSED) {
-          aggregate_window<D, MODE, MAXR>(pl, a, smem, b);
+          aggregate_window<D, MODE, LST>(pl, a, smem, b);
           __syncthreads();
         }
       }
@@ -811,10 +844,10 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   return GDN_OK;
 }
 
-template <int D, int MODE, int NT, int PROJ, int MAXR>
+template <int D, int MODE, int NT, int PROJ, int LST>
 int launch_window(const Plan& pl, const Args& a, hipStream_t stream) {
   constexpr int threads = NT;
-  auto kern = gdn_window_kernel<D, MODE, NT, PROJ, MAXR>;
+  auto kern = gdn_window_kernel<D, MODE, NT, PROJ, LST>;
   static bool attr_set = false;
   static int occ_cache_lds = -1, occ = 0;
   if (!attr_set) {
@@ -843,8 +876,13 @@ int select_maxr(const Plan& pl, const Args& a, hipStream_t st) {
   if constexpr (MODE == MODE_PROJECT) {
     return launch_window<D, MODE, NT, PROJ, 0>(pl, a, st);
   } else {
-    if (pl.pitch <= 32) return launch_window<D, MODE, NT, PROJ, 2>(pl, a, st);
-    if (pl.pitch <= 80) return launch_window<D, MODE, NT, PROJ, 5>(pl, a, st);
+    if (pl.nbr_lds) {
+      if (pl.pitch == 16) return launch_window<D, MODE, NT, PROJ, 1>(pl, a, st);
+      if (pl.pitch == 32) return launch_window<D, MODE, NT, PROJ, 2>(pl, a, st);
+      if (pl.pitch <= 80) return launch_window<D, MODE, NT, PROJ, 5>(pl, a, st);
+    } else if (pl.pitch <= 80) {
+      return launch_window<D, MODE, NT, PROJ, 6>(pl, a, st);
+    }
     return launch_window<D, MODE, NT, PROJ, 0>(pl, a, st);
   }
 }

@@ -120,6 +120,9 @@ def random_params(n, w, k, d, seed):
     dict(b=2, n=300, w=30, k=64, d=128),      # d = 128: two 16-lane rows per target
     dict(b=5, n=33, w=5, k=1, d=32),          # k = 1: every list is {self} or {other, self}
     dict(b=700, n=27, w=5, k=5, d=64),        # more windows than resident workgroups
+    dict(b=3, n=200, w=12, k=100, d=32),      # lists longer than 5 rounds: generic (recompute) variant
+    dict(b=4, n=90, w=40, k=20, d=64),        # w > 32: VALU projection in w-chunks of 16
+    dict(b=6, n=50, w=7, k=8, d=16),          # d = 16: VALU projection, one float per lane
 ], ids=lambda s: "b{b}_n{n}_w{w}_k{k}_d{d}".format(**s))
 def test_seeded_shapes_against_oracle(shape, gpu_device):
     model = random_params(shape["n"], shape["w"], shape["k"], shape["d"], seed=123)
