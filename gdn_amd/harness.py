@@ -220,7 +220,7 @@ class SeriesEvaluator:
         self.t, self.n = y_all.shape
         dev = x_all.device
         self.pred = torch.empty((self.t, self.n), dtype=torch.float32, device=dev)
-        self.ws = torch.empty((self.n, self.t), dtype=torch.float64, device=dev)
+        self.ws = ops.score_workspace(self.t, self.n, dev)
         self.med_iqr = torch.empty((self.n, 2), dtype=torch.float64, device=dev)
         self.anomaly = torch.empty((self.t,), dtype=torch.float64, device=dev)
         self.scores = torch.empty((self.n, self.t), dtype=torch.float64, device=dev) if want_scores else None

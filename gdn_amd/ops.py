@@ -162,12 +162,17 @@ def project_bwd(x, d_xlin, d_si, d_sj, d: int):
     return d_lin_w, d_a, d_c
 
 
+def score_workspace(t: int, n: int, device) -> torch.Tensor:
+    nbytes = _lib.load().gdn_score_workspace_bytes(t, n)
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=device)
+
+
 def score_quantiles(pred, gt):
     """Per-sensor median and IQR of |pred-gt| over all ticks (util/data.py:75-82), float64.
     pred, gt: fp32 [t, n].  Returns med_iqr[n, 2]."""
     pred, gt = _chk(pred, name="pred"), _chk(gt, name="gt")
     t, n = pred.shape
-    ws = torch.empty((n, t), dtype=torch.float64, device=pred.device)
+    ws = score_workspace(t, n, pred.device)
     out = torch.empty((n, 2), dtype=torch.float64, device=pred.device)
     _lib.call("gdn_score_quantiles", _ptr(pred), _ptr(gt), t, n, _ptr(ws), _ptr(out), _stream())
     return out

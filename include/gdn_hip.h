@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 1
+#define GDN_ABI_VERSION 2
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -138,12 +138,14 @@ int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, cons
  * evaluate.py:48-68 + util/data.py:75-82 + the max over sensors of evaluate.py:131-139,
  * in float64 like the reference.  pred, gt: fp32 [t,n] (time-major, as test.py returns).
  *   gdn_score_quantiles: per sensor, median and IQR (numpy 'linear' percentiles 25/75)
- *     of |pred-gt| over all t ticks -> med_iqr[n,2] float64.  workspace: t*n doubles.
+ *     of |pred-gt| over all t ticks -> med_iqr[n,2] float64.  workspace: device buffer of
+ *     gdn_score_workspace_bytes(t, n) bytes (8-byte aligned).
  *   gdn_score_smooth_max: a=(|pred-gt|-med)/(|iqr|+1e-2); 4-tap causal mean (first 3
  *     ticks of the SERIES 0); `first_tick` = series index of row 0 of this shard; when it is
  *     > 0, halo_pred/halo_gt [3,n] hold the 3 rows before it (right aligned; rows that would
  *     precede tick 0 are never read); scores[n,t] float64 (optional, NULL to skip) and
  *     anomaly[t] float64 = max over sensors.                                            */
+long long gdn_score_workspace_bytes(int t, int n);
 int gdn_score_quantiles(const float* pred, const float* gt, int t, int n,
                         double* workspace, double* med_iqr, void* stream);
 int gdn_score_smooth_max(const float* pred, const float* gt, const double* med_iqr,

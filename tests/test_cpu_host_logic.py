@@ -16,7 +16,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     entry.build()
     lib = ctypes.CDLL(_lib.LIB_PATH)
     header = open(os.path.join(ROOT, "include", "gdn_hip.h")).read()
-    declared = set(re.findall(r"^int\s+(gdn_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long long)\s+(gdn_\w+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
