@@ -865,7 +865,11 @@ int launch_window(const Plan& pl, const Args& a, hipStream_t stream) {
     }
     occ = nb; occ_cache_lds = pl.lds_bytes;
   }
-  const int grid = min(pl.batch, gdn_cu_count() * occ);
+  // every workgroup pays a prologue (neighbour lists, weights, constants): give each at least
+  // GDN_MIN_WINDOWS_PER_WG windows when the launch is small (concurrent launches on other streams
+  // fill the remaining slots)
+  static const int min_wpw = getenv("GDN_MIN_WINDOWS_PER_WG") ? atoi(getenv("GDN_MIN_WINDOWS_PER_WG")) : 1;
+  const int grid = max(1, min((pl.batch + min_wpw - 1) / min_wpw, gdn_cu_count() * occ));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), pl.lds_bytes, stream, pl, a);
   return gdn_launch_status();
 }

@@ -93,3 +93,30 @@ def test_series_evaluator_equals_per_batch_loop(use_graph, gpu_device):
     assert torch.equal(pred, ev.pred)
     _, anomaly, _ = evaluate.anomaly_scores(pred, y, device=gpu_device)
     assert torch.equal(anomaly, a1)
+
+
+@pytest.mark.parametrize("t,n,cuts", [(1000, 27, (333, 700)), (40, 5, (1, 2, 3, 5, 38)), (4100, 130, (2049,))])
+def test_sharded_smoothing_with_halo_equals_whole_series(t, n, cuts, gpu_device):
+    """The per-rank half of harness.distributed_anomaly on the GPU (first_tick > 0, 3-row halo that can
+    span several short shards), emulated in one process: shard-wise smooth/max == whole series."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(t)
+    pred = torch.rand((t, n), generator=g).to(gpu_device)
+    gt = (pred + 0.1 * torch.randn((t, n), generator=g).to(gpu_device)).contiguous()
+    med_iqr = ops.score_quantiles(pred, gt)
+    _, whole = ops.score_smooth_max(pred, gt, med_iqr, want_scores=False)
+    bounds = [0, *cuts, t]
+    parts = []
+    for s0, s1 in zip(bounds[:-1], bounds[1:]):
+        hp = hg = None
+        if s0 > 0:
+            lo = max(0, s0 - 3)
+            hp = torch.zeros((3, n), device=gpu_device)
+            hg = torch.zeros((3, n), device=gpu_device)
+            hp[3 - (s0 - lo):] = pred[lo:s0]
+            hg[3 - (s0 - lo):] = gt[lo:s0]
+        sc, an = ops.score_smooth_max(pred[s0:s1].contiguous(), gt[s0:s1].contiguous(), med_iqr,
+                                      want_scores=True, first_tick=s0, halo_pred=hp, halo_gt=hg)
+        parts.append(an)
+        assert torch.equal(sc.max(dim=0).values, an)
+    assert torch.equal(torch.cat(parts), whole)
