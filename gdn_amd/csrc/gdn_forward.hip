@@ -485,6 +485,9 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
       a.sj_out[(size_t)b * pl.n + t] = pj;
     }
   }
+  // one wave per 32-row block (its A operand is loaded once and reused for every column block).
+  // Measured alternative — dealing single 32x32 tiles round-robin so 8-wave workgroups stay busy —
+  // was slower at n = 127 (A reloaded per tile): 48 vs 55 Mwin/s.
   const int nrb = (pl.n + 31) >> 5;
   for (int rb = wv; rb < nrb; rb += nw) {
     const float* arow = xs + min(rb * 32 + l32, pl.n - 1) * XP + h;
@@ -755,19 +758,34 @@ __global__ __launch_bounds__(256) void gdn_head_kernel(const float* __restrict__
   }
   const float ob = out_b[0];
   const int rpb = blockDim.x >> 4;
-  for (int row = blockIdx.x * rpb + (threadIdx.x >> 4); row < rows; row += gridDim.x * rpb) {
-    const int s = row % n;
-    float part = 0.f;
+  constexpr int U = 4;   // rows in flight per 16-lane row group (memory-level parallelism)
+  for (int row0 = (blockIdx.x * rpb + (threadIdx.x >> 4)) * U; row0 < rows; row0 += gridDim.x * rpb * U) {
+    float zv[U][CPL], ev[U][CPL];
 #pragma unroll
-    for (int v = 0; v < CPL; ++v) {
-      float h = fmaxf(fmaf(z[(size_t)row * D + d0 + v], sc1[v], sh1[v]), 0.f);
-      h *= emb[(size_t)s * D + d0 + v];
-      h = fmaxf(fmaf(h, sc2[v], sh2[v]), 0.f);
-      if (h2) h2[(size_t)row * D + d0 + v] = h;
-      part = fmaf(h, wo[v], part);
+    for (int u = 0; u < U; ++u) {
+      const int row = min(row0 + u, rows - 1);   // clamped: loads stay unconditional
+      const int s = row % n;
+#pragma unroll
+      for (int v = 0; v < CPL; ++v) {
+        zv[u][v] = z[(size_t)row * D + d0 + v];
+        ev[u][v] = emb[(size_t)s * D + d0 + v];
+      }
     }
-    part = row16_sum(part);
-    if (l16 == 0) out[row] = part + ob;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = row0 + u;
+      float part = 0.f;
+#pragma unroll
+      for (int v = 0; v < CPL; ++v) {
+        float h = fmaxf(fmaf(zv[u][v], sc1[v], sh1[v]), 0.f);
+        h *= ev[u][v];
+        h = fmaxf(fmaf(h, sc2[v], sh2[v]), 0.f);
+        if (h2 && row < rows) h2[(size_t)row * D + d0 + v] = h;
+        part = fmaf(h, wo[v], part);
+      }
+      part = row16_sum(part);
+      if (l16 == 0 && row < rows) out[row] = part + ob;
+    }
   }
 }
 
@@ -803,6 +821,10 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   // threads: small tiles run 256-thread workgroups (several per CU), big tiles own the CU
   const int est = base_bytes + (mode != MODE_PROJECT ? nbr_bytes : 0) + n * (pl->wp + 1) * 4;
   *threads = est > 80 * 1024 ? 512 : 256;
+  if (const char* e = getenv("GDN_THREADS")) {   // tuning knob: 256 or 512
+    const int v = atoi(e);
+    if (v == 256 || v == 512) *threads = v;
+  }
   // projection on the matrix cores: d >= 32, w <= 32, whole window staged at once
   if (mode != MODE_ATTN && d >= 32 && w <= 32 && !getenv("GDN_NO_MFMA")) {
     const int wpm = w <= 16 ? 16 : 32;
@@ -976,7 +998,7 @@ extern "C" int gdn_head_fwd(const float* z, const float* emb, const float* bn1_a
   if (!z || !emb || !bn1_affine || !bn2_affine || !out_w || !out_b || !out || batch <= 0 || n <= 0)
     return GDN_ERR_ARG;
   const int rows = batch * n;
-  const int grid = min((rows + 15) / 16, gdn_cu_count() * 8);
+  const int grid = min((rows + 63) / 64, gdn_cu_count() * 8);
   hipStream_t st = (hipStream_t)stream;
   switch (d) {
     case 16: hipLaunchKernelGGL(gdn_head_kernel<16>, dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;

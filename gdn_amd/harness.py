@@ -214,9 +214,13 @@ class SeriesEvaluator:
     are captured once in a HIP graph and replayed."""
 
     def __init__(self, model, x_all: torch.Tensor, y_all: torch.Tensor, batch: int, use_graph: bool = True,
-                 want_scores: bool = False, streams: int = 4):
+                 want_scores: bool = False, streams: int = 4, coalesce: int = 1):
+        """`batch` = the logical minibatch of the reference's loader; `coalesce` consecutive batches
+        (contiguous in the resident series) go out as ONE launch — eval results do not depend on the
+        minibatch size, and launches of a few thousand windows amortise the per-workgroup prologue."""
         assert x_all.is_cuda and y_all.is_cuda
-        self.model, self.x, self.y, self.batch = model.eval(), x_all, y_all, batch
+        self.model, self.x, self.y, self.batch = model.eval(), x_all, y_all, batch * max(1, coalesce)
+        self.logical_batch, self.coalesce = batch, max(1, coalesce)
         self.t, self.n = y_all.shape
         dev = x_all.device
         self.pred = torch.empty((self.t, self.n), dtype=torch.float32, device=dev)
@@ -229,7 +233,7 @@ class SeriesEvaluator:
         self.use_graph = use_graph
         # independent batches are launched round-robin on side streams (fork/join around the
         # forward), so launches of a few hundred windows overlap and fill the chip
-        n_launch = (self.t + batch - 1) // batch
+        n_launch = (self.t + self.batch - 1) // self.batch
         self.side = [torch.cuda.Stream(device=dev) for _ in range(min(streams, n_launch))] if streams > 1 else []
 
     def _launch_forward(self):
