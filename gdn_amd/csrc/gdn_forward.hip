@@ -23,6 +23,14 @@
 #ifndef GDN_GATHER_CHUNK
 #define GDN_GATHER_CHUNK 8        // fused kernel: row fetches in flight per wave
 #endif
+// register buffers of 8 row fetches in the hand-pipelined gather: 2 = fetch(h+1) overlaps fma(h)
+#ifndef GDN_PIPE_FUSED
+#define GDN_PIPE_FUSED 3
+#endif
+#ifndef GDN_PIPE_ATTN
+#define GDN_PIPE_ATTN 3
+#endif
+#define GDN_PIPE_DEPTH(MODE) ((MODE) == MODE_ATTN ? GDN_PIPE_ATTN : GDN_PIPE_FUSED)
 #ifndef GDN_GATHER_CHUNK_ATTN
 #define GDN_GATHER_CHUNK_ATTN 4   // K8 kernel also holds the next tile's 32 prefetch registers
 #endif
@@ -270,6 +278,57 @@ __device__ __forceinline__ void gather_steps(const char* xl_lane, float al, int 
   }
 }
 
+// Half a round (8 neighbours) at a time, software-pipelined by hand: the 8 LDS fetches of the NEXT
+// half are issued before the 16 packed FMAs of the current one (the machine scheduler left to itself
+// keeps only two fetches in flight).  S0 = first rotation step of the half (0 or 8).
+template <int ROT>
+__device__ __forceinline__ int ror_i(int v) {
+  if constexpr (ROT == 0) return v;
+  else return dpp_i<0x120 + ROT>(v);
+}
+template <int ROT>
+__device__ __forceinline__ float ror_f(float v) {
+  if constexpr (ROT == 0) return v;
+  else return dpp_f<0x120 + ROT>(v);
+}
+
+template <int D, int S0, int N = 8, int S = 0>
+__device__ __forceinline__ void fetch_half(const char* xl_lane, int jb, Pack<Geo<D>::VEC> (&buf)[N]) {
+  if constexpr (S < N) {
+    buf[S] = ld_pack<Geo<D>::VEC>(reinterpret_cast<const float*>(xl_lane + ror_i<S0 + S>(jb)));
+    fetch_half<D, S0, N, S + 1>(xl_lane, jb, buf);
+  }
+}
+
+template <int D, int S0, int N = 8, int S = 0>
+__device__ __forceinline__ void fma_half(float al, const Pack<Geo<D>::VEC> (&buf)[N], Pack<Geo<D>::VEC>& acc) {
+  if constexpr (S < N) {
+    axpy_pack<Geo<D>::VEC>(ror_f<S0 + S>(al), buf[S], acc);
+    fma_half<D, S0, N, S + 1>(al, buf, acc);
+  }
+}
+
+// quarter rounds (4 neighbours), double buffered: fetch(q+1) is issued before fma(q), through all
+// MAXR rounds of the target.  Q = global quarter index 0 .. 4*MAXR-1.
+template <int D, int MAXR, int Q = 0>
+__device__ __forceinline__ void quarter_pipeline(const char* xl_lane, const float (&al)[MAXR], const int (&jb)[MAXR],
+                                                 Pack<Geo<D>::VEC> (&b0)[4], Pack<Geo<D>::VEC> (&b1)[4],
+                                                 Pack<Geo<D>::VEC>& acc) {
+  if constexpr (Q < 4 * MAXR) {
+    if constexpr (Q + 1 < 4 * MAXR) {
+      constexpr int NR = (Q + 1) / 4, NS = ((Q + 1) % 4) * 4;
+      if constexpr ((Q + 1) % 2 == 0) fetch_half<D, NS, 4>(xl_lane, jb[NR], b0);
+      else fetch_half<D, NS, 4>(xl_lane, jb[NR], b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int R = Q / 4, S0 = (Q % 4) * 4;
+    if constexpr (Q % 2 == 0) fma_half<D, S0, 4>(al[R], b0, acc);
+    else fma_half<D, S0, 4>(al[R], b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    quarter_pipeline<D, MAXR, Q + 1>(xl_lane, al, jb, b0, b1, acc);
+  }
+}
+
 struct AggCtx {
   const float* si;
   const float* sj;
@@ -327,14 +386,69 @@ __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, 
     }
     sum = row16_sum(sum);
     const float inv = __builtin_amdgcn_rcpf(sum + GDN_SOFTMAX_EPS);
+    if constexpr (MAXR <= 2) {
+      // straight-line, hand-pipelined: fetch(h+1) is issued before fma(h)
+      float al[MAXR];
+      int jb[MAXR];
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-      if (MAXR <= 2 || r < nr) {
-        const float al = e[r] * inv;
+      for (int r = 0; r < MAXR; ++r) {
+        al[r] = e[r] * inv;
+        jb[r] = jn[r] * (D * 4);
         if constexpr (MODE == MODE_ATTN) {
-          if (arow) arow[r * 16 + l16] = al;
+          if (arow) arow[r * 16 + l16] = al[r];
         }
-        gather_steps<D, 0, (MODE == MODE_ATTN ? GDN_GATHER_CHUNK_ATTN : GDN_GATHER_CHUNK)>(c.xl_lane, al, jn[r] * (D * 4), acc);
+      }
+      if constexpr (GDN_PIPE_DEPTH(MODE) == 2) {
+        Pack<G::VEC> b0[8], b1[8];
+        fetch_half<D, 0>(c.xl_lane, jb[0], b0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_half<D, 8>(c.xl_lane, jb[0], b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_half<D, 0>(al[0], b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MAXR == 2) {
+          fetch_half<D, 0>(c.xl_lane, jb[1], b0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        fma_half<D, 8>(al[0], b1, acc);
+        if constexpr (MAXR == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          fetch_half<D, 8>(c.xl_lane, jb[1], b1);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_half<D, 0>(al[1], b0, acc);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_half<D, 8>(al[1], b1, acc);
+        }
+      } else if constexpr (GDN_PIPE_DEPTH(MODE) == 3) {
+        Pack<G::VEC> q0[4], q1[4];
+        fetch_half<D, 0, 4>(c.xl_lane, jb[0], q0);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter_pipeline<D, MAXR>(c.xl_lane, al, jb, q0, q1, acc);
+      } else {
+        // one register buffer: 8 fetches in flight, then their FMAs
+        Pack<G::VEC> b0[8];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+          fetch_half<D, 0>(c.xl_lane, jb[r], b0);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_half<D, 0>(al[r], b0, acc);
+          __builtin_amdgcn_sched_barrier(0);
+          fetch_half<D, 8>(c.xl_lane, jb[r], b0);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_half<D, 8>(al[r], b0, acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) {
+        if (r < nr) {
+          const float al = e[r] * inv;
+          if constexpr (MODE == MODE_ATTN) {
+            if (arow) arow[r * 16 + l16] = al;
+          }
+          gather_steps<D, 0, (MODE == MODE_ATTN ? GDN_GATHER_CHUNK_ATTN : GDN_GATHER_CHUNK)>(c.xl_lane, al, jn[r] * (D * 4), acc);
+        }
       }
     }
   } else {
@@ -597,7 +711,7 @@ __device__ __forceinline__ void stage_x(const Plan& pl, const float* xg, float* 
 // pay the registers of the hungriest one): 0 VALU w<=8, 1 VALU w-chunks of 16,
 // 2 MFMA w<=16 (<=8 x values per thread), 3 MFMA w<=16 (<=16 per thread), 4 MFMA w<=32.
 template <int D, int MODE, int NT, int PROJ, int LST>
-__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 2)) void gdn_window_kernel(const Plan pl, const Args a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ? 3 : 2), (NT == 256 ? 3 : 2)))) void gdn_window_kernel(const Plan pl, const Args a) {
   using G = Geo<D>;
   constexpr int WCH = PROJ == 0 ? 8 : 16;
   extern __shared__ float4 smem_f4[];
