@@ -52,17 +52,30 @@ def build_model(device):
 
 
 def event_time_launches(launch, count):
-    """Average device time of `count` launches, one HIP event pair per launch on the launch stream."""
-    pairs = []
-    for i in range(count):
+    """Average device time per launch: `count` back-to-back launches on the launch stream between two
+    HIP events (the queue never drains, so this is kernel time + the ~1.5 us dependent-launch gap; an
+    event pair per launch adds ~5 us of its own and was dropped).  Repeated 3x, (mean, best) in us."""
+    runs = []
+    for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        launch(i)
+        for i in range(count):
+            launch(i)
         e1.record()
-        pairs.append((e0, e1))
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in pairs)
-    return 1e3 * sum(ts) / len(ts), 1e3 * ts[len(ts) // 2]     # mean, median in microseconds
+        torch.cuda.synchronize()
+        runs.append(1e3 * e0.elapsed_time(e1) / count)
+    return sum(runs) / len(runs), min(runs)
+
+
+def pmc_traffic(kernel_key, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) for this launch size, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            rec = json.load(f)["per_launch"][kernel_key][str(batch)]
+        return int(rec["fetch_bytes"] + rec["write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def k8_roofline(model, x, batch, launches):
@@ -102,8 +115,8 @@ def k8_roofline(model, x, batch, launches):
     achieved = alg_bytes / (mean_us * 1e-6) / 1e9
     return {"kernel": "gdn_attn_aggregate_fwd (K8 gather-aggregate, staged eval leg, fp32 storage)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "launch_us": round(mean_us, 2), "launch_us_median": round(med_us, 2), "batch": batch,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k8", batch),
+            "launch_us": round(mean_us, 2), "launch_us_best": round(med_us, 2), "batch": batch,
             "algorithmic_bytes_per_launch": alg_bytes,
             "staged_pipeline_us": {"project": round(proj_us, 2), "attn_aggregate": round(mean_us, 2),
                                    "head": round(head_us, 2)}}
@@ -135,8 +148,8 @@ def fused_roofline(model, x, pred, batch, launches):
     lds_bytes = batch * N_SENSORS * 32 * DIM * 4
     return {"kernel": "gdn_forward_fused (dominant kernel of the timed region; serial launches)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "launch_us": round(mean_us, 2), "launch_us_median": round(med_us, 2), "batch": batch,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused", batch),
+            "launch_us": round(mean_us, 2), "launch_us_best": round(med_us, 2), "batch": batch,
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "by design only x-in + out touch HBM; the kernel is bound by the LDS row gather / fp32 VALU",
             "lds_gather_TBps": round(lds_bytes / (mean_us * 1e-6) / 1e12, 2)}
