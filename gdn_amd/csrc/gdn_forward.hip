@@ -104,11 +104,16 @@ struct Plan {
   int wl_lds;    // 1: lin.weight staged (permuted) in LDS, 0: lane blocks loaded from global
   int mfma;      // 1: projection on v_mfma_f32_32x32x2_f32 (x tile at odd pitch xp = wpm + 1)
   int wpm, xp;   // MFMA path: padded window (16 / 32) and x-tile pitch in floats
+  int dfull;     // row stride of xlin / z / emb / lin.weight rows in global memory (= model dim)
+  int nslices;   // gridDim.y: column slices of width d when the full-width tile exceeds LDS
   int off_xl, off_si, off_sj, off_deg, off_wl, off_nbr, off_xs;  // float offsets
   int lds_bytes;
 };
 
 enum { MODE_PROJECT = 0, MODE_ATTN = 1, MODE_FUSED = 2 };
+
+// first model column of this workgroup's slice (gridDim.y slices of the tile width)
+#define GDN_COL0(D) ((int)blockIdx.y * (D))
 
 struct Args {
   // inputs
@@ -155,7 +160,7 @@ __device__ __forceinline__ void stage_weights(const Plan& pl, const Args& a, flo
     const int wc = r / ((WCH / 4) * G::VEC);
     const int col = wc * WCH + c4 * 4 + e;
     const int drow = slot * G::VEC + vv;
-    wlds[t] = col < pl.w ? a.lin_w[(size_t)drow * pl.w + col] : 0.f;
+    wlds[t] = col < pl.w ? a.lin_w[(size_t)(GDN_COL0(D) + drow) * pl.w + col] : 0.f;
   }
 }
 
@@ -173,7 +178,7 @@ __device__ __forceinline__ void load_lane_weights(const Plan& pl, const Args& a,
 #pragma unroll
       for (int c = 0; c < WCH; ++c) {
         const int col = wc * WCH + c;
-        wl[v][c] = col < pl.w ? a.lin_w[(size_t)(d0 + v) * pl.w + col] : 0.f;
+        wl[v][c] = col < pl.w ? a.lin_w[(size_t)(GDN_COL0(D) + d0 + v) * pl.w + col] : 0.f;
       }
     return;
   }
@@ -231,7 +236,7 @@ __device__ __forceinline__ void project_chunk(const Plan& pl, const Args& a, flo
       }
       si[row] = pi;
       sj[row] = pj;
-      if (TO_GLOBAL && last) {
+      if (TO_GLOBAL && last && blockIdx.y == 0) {
         a.si_out[(size_t)b * pl.n + row] = pi;
         a.sj_out[(size_t)b * pl.n + row] = pj;
       }
@@ -248,7 +253,8 @@ __device__ __forceinline__ void project_chunk(const Plan& pl, const Args& a, flo
 #pragma unroll
       for (int v = 0; v < G::VEC; ++v) acc.v[v] = fmaf(xr[c], wl[v][c], acc.v[v]);
     st_pack<G::VEC>(xl + (size_t)row * D + d0, acc);
-    if (TO_GLOBAL && last) st_pack<G::VEC>(a.xlin_out + ((size_t)b * pl.n + row) * D + d0, acc);
+    if (TO_GLOBAL && last)
+      st_pack<G::VEC>(a.xlin_out + ((size_t)b * pl.n + row) * pl.dfull + GDN_COL0(D) + d0, acc);
   }
 }
 
@@ -360,7 +366,7 @@ __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, 
   const int row0 = i * pl.pitch;
   float* arow = nullptr;
   if constexpr (MODE == MODE_ATTN) {
-    if (a.alpha && slice == 0) arow = a.alpha + ((size_t)b * pl.n + i) * pl.pitch;
+    if (a.alpha && slice == 0 && blockIdx.y == 0) arow = a.alpha + ((size_t)b * pl.n + i) * pl.pitch;
   }
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
@@ -498,27 +504,28 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
   c.xl_lane = reinterpret_cast<const char*>(smem + pl.off_xl + d0);
 
   // per-lane constants of the epilogue
-  const Pack<G::VEC> bias = ld_pack<G::VEC>(a.gnn_bias + d0);
+  const int gcol = GDN_COL0(D) + d0;   // this lane's first MODEL column
+  const Pack<G::VEC> bias = ld_pack<G::VEC>(a.gnn_bias + gcol);
   Pack<G::VEC> sc1, sh1, sc2, sh2, wo;
   float out_b = 0.f;
   if constexpr (MODE == MODE_FUSED) {
-    sc1 = ld_pack<G::VEC>(a.bn1 + d0);
-    sh1 = ld_pack<G::VEC>(a.bn1 + D + d0);
-    sc2 = ld_pack<G::VEC>(a.bn2 + d0);
-    sh2 = ld_pack<G::VEC>(a.bn2 + D + d0);
-    wo = ld_pack<G::VEC>(a.out_w + d0);
-    out_b = a.out_b[0];
+    sc1 = ld_pack<G::VEC>(a.bn1 + gcol);
+    sh1 = ld_pack<G::VEC>(a.bn1 + pl.dfull + gcol);
+    sc2 = ld_pack<G::VEC>(a.bn2 + gcol);
+    sh2 = ld_pack<G::VEC>(a.bn2 + pl.dfull + gcol);
+    wo = ld_pack<G::VEC>(a.out_w + gcol);
+    out_b = blockIdx.y == 0 ? a.out_b[0] : 0.f;
   }
 
   for (int i = slot; i < pl.n; i += tpp) {
     Pack<G::VEC> emb_i;
-    if constexpr (MODE == MODE_FUSED) emb_i = ld_pack<G::VEC>(a.emb + (size_t)i * D + d0);
+    if constexpr (MODE == MODE_FUSED) emb_i = ld_pack<G::VEC>(a.emb + (size_t)i * pl.dfull + gcol);
     Pack<G::VEC> acc;
     aggregate_target<D, MODE, (LST == 6 ? 5 : LST), (LST >= 1 && LST <= 5)>(pl, a, c, b, i, slice, l16, acc);
 #pragma unroll
     for (int v = 0; v < G::VEC; ++v) acc.v[v] += bias.v[v];
     if constexpr (MODE == MODE_ATTN) {
-      st_pack<G::VEC>(a.z + ((size_t)b * pl.n + i) * D + d0, acc);
+      st_pack<G::VEC>(a.z + ((size_t)b * pl.n + i) * pl.dfull + gcol, acc);
     } else {
       float part = 0.f;
 #pragma unroll
@@ -530,7 +537,10 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
       }
       part = row16_sum(part);
       if constexpr (G::NS == 2) part += __shfl_xor(part, 16);
-      if (l16 == 0 && slice == 0) a.out[(size_t)b * pl.n + i] = part + out_b;
+      if (l16 == 0 && slice == 0) {
+        if (pl.nslices == 1) a.out[(size_t)b * pl.n + i] = part + out_b;
+        else atomicAdd(&a.out[(size_t)b * pl.n + i], part + out_b);   // out zeroed by the launcher
+      }
     }
   }
 }
@@ -595,8 +605,10 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
     si[t] = pi;
     sj[t] = pj;
     if constexpr (MODE == MODE_PROJECT) {
-      a.si_out[(size_t)b * pl.n + t] = pi;
-      a.sj_out[(size_t)b * pl.n + t] = pj;
+      if (blockIdx.y == 0) {
+        a.si_out[(size_t)b * pl.n + t] = pi;
+        a.sj_out[(size_t)b * pl.n + t] = pj;
+      }
     }
   }
   // one wave per 32-row block (its A operand is loaded once and reused for every column block).
@@ -622,7 +634,7 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
         if (row < pl.n) {
           xl[row * D + cb * 32 + l32] = acc[r];
           if constexpr (MODE == MODE_PROJECT)
-            a.xlin_out[((size_t)b * pl.n + row) * D + cb * 32 + l32] = acc[r];
+            a.xlin_out[((size_t)b * pl.n + row) * pl.dfull + GDN_COL0(D) + cb * 32 + l32] = acc[r];
         }
       }
     }
@@ -643,7 +655,7 @@ __device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, 
 #pragma unroll
     for (int kk = 0; kk < WPM / 2; ++kk) {
       const int k = 2 * kk + h;
-      wb[cb][kk] = k < pl.w ? a.lin_w[(size_t)(cb * 32 + l32) * pl.w + k] : 0.f;
+      wb[cb][kk] = k < pl.w ? a.lin_w[(size_t)(GDN_COL0(D) + cb * 32 + l32) * pl.w + k] : 0.f;
     }
   const int cnt = pl.n * pl.w;
   const float inv_w = 1.0f / (float)pl.w;
@@ -749,7 +761,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
       float4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;
       float psi, psj;
       const int tn = min(tid, pl.n - 1);
-#define GDN_PRE_LOAD(u) pre##u = src[min(tid + u * nth, nvec - 1)];
+#define GDN_PRE_LOAD(u)                                                   \
+  {                                                                       \
+    const int tt = min(tid + u * nth, nvec - 1);                          \
+    pre##u = src[(size_t)(tt / (D / 4)) * (pl.dfull / 4) + tt % (D / 4)]; \
+  }
 #define GDN_PRE_STORE(u)              \
   {                                   \
     const int t = tid + u * nth;      \
@@ -757,7 +773,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
   }
 #define GDN_PRE_ALL(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
       {
-        const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)blockIdx.x * pl.n * D);
+        const float4* src =
+            reinterpret_cast<const float4*>(a.xlin_in + (size_t)blockIdx.x * pl.n * pl.dfull + GDN_COL0(D));
         GDN_PRE_ALL(GDN_PRE_LOAD)
         psi = a.si_in[(size_t)blockIdx.x * pl.n + tn];
         psj = a.sj_in[(size_t)blockIdx.x * pl.n + tn];
@@ -771,7 +788,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
         __syncthreads();
         const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round re-reads its own tile
         {
-          const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)nb * pl.n * D);
+          const float4* src =
+              reinterpret_cast<const float4*>(a.xlin_in + (size_t)nb * pl.n * pl.dfull + GDN_COL0(D));
           GDN_PRE_ALL(GDN_PRE_LOAD)
           psi = a.si_in[(size_t)nb * pl.n + tn];
           psj = a.sj_in[(size_t)nb * pl.n + tn];
@@ -784,8 +802,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
 #undef GDN_PRE_LOAD
     } else {
       for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
-        const float4* src = reinterpret_cast<const float4*>(a.xlin_in + (size_t)b * pl.n * D);
-        for (int t = tid; t < nvec; t += nth) tile4[t] = src[t];
+        const float4* src =
+            reinterpret_cast<const float4*>(a.xlin_in + (size_t)b * pl.n * pl.dfull + GDN_COL0(D));
+        for (int t = tid; t < nvec; t += nth)
+          tile4[t] = src[(size_t)(t / (D / 4)) * (pl.dfull / 4) + t % (D / 4)];
         for (int t = tid; t < pl.n; t += nth) {
           si[t] = a.si_in[(size_t)b * pl.n + t];
           sj[t] = a.sj_in[(size_t)b * pl.n + t];
@@ -909,6 +929,14 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (n > 4096) return GDN_ERR_UNSUPPORTED;
   pl->n = n; pl->d = d; pl->w = w; pl->k = k; pl->batch = batch;
+  pl->dfull = d; pl->nslices = 1;
+  if (d == 128 && (n + 1) * d * 4 + 4 * (n + 8) * 4 > 150 * 1024) {
+    // the full-width tile does not fit LDS: two workgroups per window, 64 columns each (the
+    // attention scalars do not depend on the slice; the head sums the slices' partial outputs)
+    d = 64;
+    pl->d = 64;
+    pl->nslices = 2;
+  }
   pl->wp = 0; pl->pitch = 0; pl->xrows = 0; pl->nbr_lds = 0;
   if (mode != MODE_ATTN) {
     if (w <= 0) return GDN_ERR_ARG;
@@ -1006,7 +1034,7 @@ int launch_window(const Plan& pl, const Args& a, hipStream_t stream) {
   // fill the remaining slots)
   static const int min_wpw = getenv("GDN_MIN_WINDOWS_PER_WG") ? atoi(getenv("GDN_MIN_WINDOWS_PER_WG")) : 1;
   const int grid = max(1, min((pl.batch + min_wpw - 1) / min_wpw, gdn_cu_count() * occ));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), pl.lds_bytes, stream, pl, a);
+  hipLaunchKernelGGL(kern, dim3(grid, pl.nslices), dim3(threads), pl.lds_bytes, stream, pl, a);
   return gdn_launch_status();
 }
 
@@ -1103,6 +1131,9 @@ extern "C" int gdn_forward_fused(const float* x, const float* lin_w, const float
   a.x = x; a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.deg = deg;
   a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;
   a.out_w = out_w; a.out_b = out_b; a.out = out;
+  if (pl.nslices > 1 &&   // the slices add their partial head outputs into `out`
+      hipMemsetAsync(out, 0, (size_t)batch * n * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return GDN_ERR_LAUNCH;
   return dispatch_window<MODE_FUSED>(pl, a, threads, (hipStream_t)stream);
 }
 

@@ -38,152 +38,10 @@ __global__ __launch_bounds__(256) void score_delta_kernel(const float* __restric
   }
 }
 
-// One workgroup per sensor: MSB-first radix select (8-bit digits) of NQ ranks at once over the
-// sensor's t keys (non-negative doubles order like their bit patterns).  Ranks whose prefixes
-// still coincide share one histogram.
-//  * KPT > 0: every thread keeps KPT keys in registers for all 8 passes (t <= KPT * blockDim) plus
-//    an ALIVE bit per key: a key that matches no rank's prefix can never match again, so after
-//    the first two or three digits almost every wave skips its keys and the late passes are free;
-//    KPT == 0: keys are re-read from memory each pass (any t).
-//  * a whole wave landing in one bin (the exponent bytes) does one add of 64;
-//  * the bin holding each rank is found by one wave per rank with a shuffle scan (not a serial
-//    walk over 256 LDS words).
-template <int KPT>
-__global__ __launch_bounds__(1024) void score_select_kernel(const double* __restrict__ ws, int t,
-                                                            const SelectArgs sa, double* __restrict__ med_iqr) {
-  __shared__ unsigned int hist[NQ][256];
-  __shared__ unsigned long long prefix[NQ];
-  __shared__ int rem[NQ];
-  __shared__ int rep[NQ];
-  const int s = blockIdx.x;
-  const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(ws) + (size_t)s * t;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  constexpr int NK = KPT > 0 ? KPT : 1;
-  unsigned long long kreg[NK];
-  unsigned int alive = 0u;
-  if constexpr (KPT > 0) {
-#pragma unroll
-    for (int u = 0; u < KPT; ++u) {
-      const int i = tid + u * nth;
-      kreg[u] = keys[min(i, t - 1)];                          // unconditional, clamped
-      if (i < t) alive |= 1u << u;
-    }
-  }
-  if (tid < NQ) {
-    prefix[tid] = 0ull;
-    rem[tid] = sa.rank[tid];
-  }
-  __syncthreads();
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = 56 - 8 * pass;
-    if (tid < NQ) {
-      int r = tid;
-      for (int q = tid - 1; q >= 0; --q)
-        if (prefix[q] == prefix[tid]) r = q;
-      rep[tid] = r;
-    }
-    for (int i = tid; i < NQ * 256; i += nth) (&hist[0][0])[i] = 0u;
-    __syncthreads();
-    unsigned long long pf[NQ];
-    bool active[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      pf[q] = prefix[q];
-      active[q] = rep[q] == q;
-    }
-    // returns whether the key still matches some rank's prefix
-    auto tally = [&](unsigned long long key, bool live) -> bool {
-      const unsigned int digit = (unsigned int)(key >> shift) & 255u;
-      const unsigned int d0 = __builtin_amdgcn_readfirstlane(digit);
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (!active[q]) continue;   // uniform
-        // high bits above this digit must equal the prefix (pass 0: no high bits)
-        const bool match = live && (pass == 0 ? true : ((key ^ pf[q]) >> (shift + 8)) == 0ull);
-        any |= match;
-        if (__all(match && digit == d0)) {
-          if (lane == 0) atomicAdd(&hist[q][d0], 64u);   // whole wave in one bin: one add of 64
-        } else if (match) {
-          atomicAdd(&hist[q][digit], 1u);
-        }
-      }
-      return any;
-    };
-    if constexpr (KPT > 0) {
-#pragma unroll
-      for (int u = 0; u < KPT; ++u) {
-        const bool live = (alive >> u) & 1u;
-        if (__any(live)) {                       // wave-uniform skip of dead keys
-          if (!tally(kreg[u], live)) alive &= ~(1u << u);
-        }
-      }
-    } else {
-      for (int i0 = 0; i0 < t; i0 += 4 * nth) {
-        unsigned long long k4[4];
-        bool l4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + tid + u * nth;
-          k4[u] = keys[min(i, t - 1)];
-          l4[u] = i < t;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) tally(k4[u], l4[u]);
-      }
-    }
-    __syncthreads();
-    // wave q locates rank q's bin: lane l owns bins 4l..4l+3, inclusive scan over lanes
-    if (wv < NQ) {
-      const unsigned int* h = hist[rep[wv]];
-      const uint4 c4 = *reinterpret_cast<const uint4*>(h + 4 * lane);
-      const int mine = (int)(c4.x + c4.y + c4.z + c4.w);
-      int incl = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-      }
-      const int left0 = rem[wv];
-      const int excl = incl - mine;
-      // the owning lane is the first whose inclusive count exceeds the remaining rank
-      const bool owner = left0 >= excl && left0 < incl;
-      if (owner) {
-        int left = left0 - excl, bin = 4 * lane;
-        const int c[4] = {(int)c4.x, (int)c4.y, (int)c4.z, (int)c4.w};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (left >= c[j] && bin == 4 * lane + j) {
-            left -= c[j];
-            bin += 1;
-          }
-        }
-        prefix[wv] |= (unsigned long long)bin << shift;
-        rem[wv] = left;
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    double v[NQ];
-    for (int q = 0; q < NQ; ++q) v[q] = __longlong_as_double((long long)prefix[q]);
-    const double med = sa.median_pair ? (v[0] + v[1]) / 2.0 : v[0];
-    double qv[2];
-    for (int h = 0; h < 2; ++h) {   // numpy _lerp
-      const double a = v[2 + 2 * h], b = v[3 + 2 * h], g = sa.gamma[h];
-      const double diff = b - a;
-      double r = a + diff * g;
-      if (g >= 0.5) r = b - diff * (1.0 - g);
-      qv[h] = r;
-    }
-    med_iqr[2 * s] = med;
-    med_iqr[2 * s + 1] = qv[1] - qv[0];
-  }
-}
-
-// ------------------------------------------------------------------ wide radix select
-// Same MSB-first 8-bit radix select, spread over the whole chip: one launch per digit, grid =
+// ------------------------------------------------------------------ radix select
+// Exact order statistics by an MSB-first 8-bit radix select of NQ ranks per sensor over the sensor's t
+// keys (non-negative doubles order like their bit patterns), spread over the whole chip: one launch per
+// digit, grid =
 // (key slices of 2048, sensors).  A block keeps its <= 2048 keys in registers (8 per thread),
 // histograms the current digit of the keys that still match some rank's prefix in LDS, adds its
 // non-empty bins to the sensor's global histogram, and takes a ticket; the LAST block of a sensor
@@ -568,11 +426,6 @@ extern "C" int gdn_score_quantiles(const float* pred, const float* gt, int t, in
     sa.rank[2 + 2 * h] = ilo;
     sa.rank[3 + 2 * h] = ihi;
     sa.gamma[h] = vi - lo;
-  }
-  static const bool narrow = getenv("GDN_SELECT_NARROW") != nullptr;   // A/B switch for profiling
-  if (narrow && t <= 32 * 1024) {
-    hipLaunchKernelGGL(score_select_kernel<32>, dim3(n), dim3(1024), 0, st, workspace, t, sa, med_iqr);
-    return gdn_launch_status();
   }
   unsigned long long* bufA = reinterpret_cast<unsigned long long*>(workspace);
   unsigned long long* bufB = bufA + (size_t)t * n;

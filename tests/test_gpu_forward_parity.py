@@ -118,6 +118,7 @@ def random_params(n, w, k, d, seed):
     dict(b=128, n=64, w=15, k=64, d=64),      # BASELINE config 2 (fully connected), full size
     dict(b=3, n=512, w=30, k=64, d=64),       # BASELINE config 5 shape (big LDS tile, x chunking)
     dict(b=2, n=300, w=30, k=64, d=128),      # d = 128: two 16-lane rows per target
+    dict(b=3, n=512, w=30, k=64, d=128),      # BASELINE config 5 at d=128: tile > LDS -> 2 column slices
     dict(b=5, n=33, w=5, k=1, d=32),          # k = 1: every list is {self} or {other, self}
     dict(b=700, n=27, w=5, k=5, d=64),        # more windows than resident workgroups
     dict(b=3, n=200, w=12, k=100, d=32),      # lists longer than 5 rounds: generic (recompute) variant
@@ -150,3 +151,23 @@ def test_cpu_tensors_are_refused_loudly():
     model = GDN([torch.zeros((2, 1), dtype=torch.long)], 8, dim=16, input_dim=4, topk=3).eval()
     with pytest.raises(GdnHipError):
         model(torch.rand((2, 8, 4)), None)
+
+
+def test_zero_norm_embedding_row_reproduces_reference_nan_behaviour(gpu_device):
+    """models/GDN.py:152 divides by the norm product without an epsilon: a zero embedding row makes
+    its cosines NaN, and torch.topk ranks NaN above every number.  Reproduced, not "fixed"."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, d, k = 20, 32, 5
+    emb = torch.randn((n, d), generator=g)
+    emb[7] = 0.0
+    graph = ops.topk_graph(emb.to(gpu_device), k, want_cos=True)
+    cos = graph.cos.cpu()
+    assert torch.isnan(cos[7]).all() and torch.isnan(cos[:, 7]).all()
+    ref = gdn_oracle.learned_graph(emb, k)
+    got = graph.topk.cpu()
+    for i in range(n):
+        if i == 7:
+            continue            # an all-NaN row: torch's pick among equal keys is unspecified
+        assert got[i, 0] == 7   # the NaN column ranks first
+        assert got[i].tolist() == ref[i].tolist()
