@@ -1,15 +1,18 @@
 // Backward of the GraphLayer hot path (training, reference train.py:72 `loss.backward()`
 // restricted to models/graph_layer.py:53-117).  Same decomposition as the forward: one
-// workgroup per window, 16-lane DPP rows own one target at a time, the (row-offset, value)
-// pair of each neighbour rotates through the row.
+// workgroup per window, 16-lane DPP rows own one sensor at a time, (row-offset, weight) pairs
+// rotate through the row.  No scatter: both directions are GATHERS.
 //
 //   z_i = sum_p alpha_ip * xlin[j_p] + bias
-//   d_alpha_ip = d_z_i . xlin[j_p]                       (partial dots ride the rotation)
-//   d_e_ip     = alpha_ip * (d_alpha_ip - sum_q alpha_iq d_alpha_iq)      (softmax)
-//   d_pi_ip    = d_e_ip * (pi_ip > 0 ? 1 : 0.2)                            (LeakyReLU)
-//   d_s_i[i]  += sum_p d_pi_ip ;  d_s_j[j_p] += d_pi_ip ;  d_xlin[j_p] += alpha_ip * d_z_i
-// Scatter targets (d_xlin, d_s_j) are accumulated in LDS with ds_add_f32 — sources and
-// targets of a window live in the same workgroup — and written out once per window.
+//   pass 1 (per TARGET i, xlin tile in LDS):
+//     d_alpha_ip = d_z_i . xlin[j_p]          partial dots of the 16 lanes are rotated home
+//     d_e_ip     = alpha_ip * (d_alpha_ip - sum_q alpha_iq d_alpha_iq)          (softmax)
+//     d_pi_ip    = d_e_ip * (pi_ip > 0 ? 1 : 0.2)                               (LeakyReLU)
+//     d_s_i[i]   = sum_p d_pi_ip ;  alpha and d_pi are kept in two [n, pitch] LDS tables
+//   pass 2 (per SOURCE j, d_z tile in LDS, REVERSE lists: the (target, slot) pairs that name j):
+//     d_xlin[j]  = sum_(i,p) alpha_ip * d_z_i ;  d_s_j[j] = sum_(i,p) d_pi_ip
+// Results are bitwise reproducible (fixed list order); the first version scattered with ds_add_f32
+// and spent 650 us per 512 windows where the forward needs 17.
 #include "gdn_common.hpp"
 
 namespace {
@@ -32,6 +35,12 @@ __device__ __forceinline__ PackB<V> ldp(const float* p) {
   }
   return r;
 }
+template <int V>
+__device__ __forceinline__ void stp(float* p, const PackB<V>& r) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  else if constexpr (V == 2) *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+  else *p = r.v[0];
+}
 
 template <int D>
 struct GeoB {
@@ -40,9 +49,52 @@ struct GeoB {
   static constexpr int NS = D / DS;
 };
 
+template <int ROT>
+__device__ __forceinline__ int rorb_i(int v) {
+  if constexpr (ROT == 0) return v;
+  else return dpp_i<0x120 + ROT>(v);
+}
+template <int ROT>
+__device__ __forceinline__ float rorb_f(float v) {
+  if constexpr (ROT == 0) return v;
+  else return dpp_f<0x120 + ROT>(v);
+}
+
+// tsum (home lane q) = sum over the 16 lanes of g . tile[row of neighbour q][lane's columns]:
+// at step S lane l holds neighbour (l+S)%16's row offset; its partial dot is rotated by 16-S lanes
+// back to the neighbour's home lane.  Every step is independent of the others.
+template <int D, int S = 0>
+__device__ __forceinline__ void dot_steps(const char* tile_lane, int jb, const PackB<GeoB<D>::VEC>& g,
+                                          float& tsum) {
+  if constexpr (S < 16) {
+    const PackB<GeoB<D>::VEC> src =
+        ldp<GeoB<D>::VEC>(reinterpret_cast<const float*>(tile_lane + rorb_i<S>(jb)));
+    float part = 0.f;
+#pragma unroll
+    for (int v = 0; v < GeoB<D>::VEC; ++v) part = fmaf(g.v[v], src.v[v], part);
+    tsum += rorb_f<(16 - S) & 15>(part);
+    if constexpr (S == 7) __builtin_amdgcn_sched_barrier(0);
+    dot_steps<D, S + 1>(tile_lane, jb, g, tsum);
+  }
+}
+
+// acc += a_q * tile[row q] for the 16 (weight, row) pairs held by the lanes of this row
+template <int D, int S = 0>
+__device__ __forceinline__ void axpy_steps(const char* tile_lane, float a, int rb, PackB<GeoB<D>::VEC>& acc) {
+  if constexpr (S < 16) {
+    const PackB<GeoB<D>::VEC> src =
+        ldp<GeoB<D>::VEC>(reinterpret_cast<const float*>(tile_lane + rorb_i<S>(rb)));
+    const float a_s = rorb_f<S>(a);
+#pragma unroll
+    for (int v = 0; v < GeoB<D>::VEC; ++v) acc.v[v] = fmaf(a_s, src.v[v], acc.v[v]);
+    if constexpr (S == 7) __builtin_amdgcn_sched_barrier(0);
+    axpy_steps<D, S + 1>(tile_lane, a, rb, acc);
+  }
+}
+
 struct BwdPlan {
-  int n, d, k, pitch, batch;
-  int off_xl, off_dxl, off_sj, off_dsj, off_dbias, off_deg, off_dal, off_nbr;  // float offsets
+  int n, d, k, pitch, rpitch, batch;
+  int off_tile, off_sj, off_al, off_dpi, off_dbias;  // float offsets
   int lds_bytes;
 };
 
@@ -50,135 +102,154 @@ template <int D>
 __global__ __launch_bounds__(256) void gdn_attn_bwd_kernel(
     const BwdPlan pl, const float* __restrict__ d_z, const float* __restrict__ xlin,
     const float* __restrict__ alpha, const float* __restrict__ s_i, const float* __restrict__ s_j,
-    const uint16_t* __restrict__ nbr_g, const int32_t* __restrict__ deg_g, float* __restrict__ d_xlin,
-    float* __restrict__ d_si, float* __restrict__ d_sj, float* __restrict__ d_bias) {
+    const uint16_t* __restrict__ nbr, const uint32_t* __restrict__ rent, const int32_t* __restrict__ rlen,
+    float* __restrict__ d_xlin, float* __restrict__ d_si, float* __restrict__ d_sj,
+    float* __restrict__ d_bias) {
   using G = GeoB<D>;
   extern __shared__ float4 smem_b4[];
   float* smem = reinterpret_cast<float*>(smem_b4);
-  float* xl = smem + pl.off_xl;
-  float* dxl = smem + pl.off_dxl;
+  float* tile = smem + pl.off_tile;    // xlin (pass 1) then d_z (pass 2); row n stays 0
   float* sj = smem + pl.off_sj;
-  float* dsj = smem + pl.off_dsj;
+  float* al_t = smem + pl.off_al;      // alpha  [n, pitch]
+  float* dpi_t = smem + pl.off_dpi;    // d_pi   [n, pitch]
   float* dbias = smem + pl.off_dbias;
-  uint16_t* degs = reinterpret_cast<uint16_t*>(smem + pl.off_deg);
-  uint16_t* nbr = reinterpret_cast<uint16_t*>(smem + pl.off_nbr);
   const int tid = threadIdx.x, nth = blockDim.x;
   const int grp = tid >> 4, l16 = tid & 15;
   const int slot = grp / G::NS, slice = grp % G::NS;
   const int tpp = (nth >> 4) / G::NS;
   const int d0 = slice * 64 + l16 * G::VEC;
-  float* dal = smem + pl.off_dal + grp * pl.pitch;  // this row's d_alpha scratch
+  const char* tile_lane = reinterpret_cast<const char*>(tile + d0);
+  const int rounds = pl.pitch >> 4;
 
-  for (int t = tid; t < pl.n; t += nth) degs[t] = (uint16_t)deg_g[t];
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(nbr_g);
-    uint4* dst = reinterpret_cast<uint4*>(nbr);
-    const int nvec = pl.n * pl.pitch / 8;
-    for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
-  }
   for (int t = tid; t < D; t += nth) {
     dbias[t] = 0.f;
-    xl[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
+    tile[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
   }
   if (tid == 0) sj[pl.n] = 0.f;
   PackB<G::VEC> bias_acc;
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] = 0.f;
+  const int nvec = pl.n * D / 4;
 
   for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
     const size_t row0 = (size_t)b * pl.n;
     {
       const float4* src = reinterpret_cast<const float4*>(xlin + row0 * D);
-      float4* dst = reinterpret_cast<float4*>(xl);
-      float4* zdst = reinterpret_cast<float4*>(dxl);
-      const int nvec = pl.n * D / 4;
-      for (int t = tid; t < nvec; t += nth) {
-        dst[t] = src[t];
-        zdst[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      for (int t = tid; t < pl.n; t += nth) {
-        sj[t] = s_j[row0 + t];
-        dsj[t] = 0.f;
-      }
+      float4* dst = reinterpret_cast<float4*>(tile);
+      for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
+      for (int t = tid; t < pl.n; t += nth) sj[t] = s_j[row0 + t];
     }
     __syncthreads();
 
+    // ---- pass 1: per target
     for (int i = slot; i < pl.n; i += tpp) {
-      const int degi = degs[i];
-      const int rounds = (degi + 15) >> 4;
       const uint16_t* nrow = nbr + (size_t)i * pl.pitch;
       const float* arow = alpha + (row0 + i) * pl.pitch;
       const PackB<G::VEC> g = ldp<G::VEC>(d_z + (row0 + i) * D + d0);
 #pragma unroll
       for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] += g.v[v];
       const float sti = s_i[row0 + i];
-
-      // pass A: d_alpha of every neighbour (partial dots ride the rotation), and sum alpha*d_alpha
       float dot = 0.f;
       for (int r = 0; r < rounds; ++r) {
         const int p = r * 16 + l16;
-        int jb = nrow[p] * (D * 4);
+        const int j = nrow[p];            // padding = sentinel n (zero row, alpha 0)
         float tsum = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const PackB<G::VEC> src =
-              ldp<G::VEC>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(xl + d0) + jb));
-#pragma unroll
-          for (int v = 0; v < G::VEC; ++v) tsum = fmaf(g.v[v], src.v[v], tsum);
-          tsum = dpp_f<GDN_DPP_ROR1>(tsum);
-          jb = dpp_i<GDN_DPP_ROR1>(jb);
-        }
-        // after 16 steps tsum is back on its home lane holding the full dot over this slice
+        dot_steps<D>(tile_lane, j * (D * 4), g, tsum);
         if constexpr (G::NS == 2) tsum += __shfl_xor(tsum, 16);
-        const float al = p < degi ? arow[p] : 0.f;
+        const float al = arow[p];
         dot = fmaf(al, tsum, dot);
-        dal[p] = tsum;  // per-lane scratch: read back only by this lane in pass B
+        if (slice == 0) {
+          al_t[i * pl.pitch + p] = al;
+          dpi_t[i * pl.pitch + p] = tsum;   // d_alpha for now; finished below
+        }
       }
       dot = row16_sum(dot);
-      // pass B: logits' gradients and the two scatters
       float dsi = 0.f;
-      for (int r = 0; r < rounds; ++r) {
-        const int p = r * 16 + l16;
-        const int j = nrow[p];
-        const float al = p < degi ? arow[p] : 0.f;
-        const float dalp = dal[p];
-        const float de = al * (dalp - dot);
-        const float pi = sti + sj[j];
-        const float dpi = de * (pi > 0.f ? 1.f : GDN_NEG_SLOPE);
-        if (p < degi && slice == 0) {
+      if (slice == 0) {
+        for (int r = 0; r < rounds; ++r) {
+          const int p = r * 16 + l16;
+          const int j = nrow[p];
+          const float al = al_t[i * pl.pitch + p];      // written by this lane above
+          const float de = al * (dpi_t[i * pl.pitch + p] - dot);
+          const float pi = sti + sj[j];
+          const float dpi = de * (pi > 0.f ? 1.f : GDN_NEG_SLOPE);
+          dpi_t[i * pl.pitch + p] = dpi;
           dsi += dpi;
-          atomicAdd(&dsj[j], dpi);  // ds_add_f32
-        }
-        float a_rot = al;
-        int jb = j * (D * 4);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(dxl + d0) + jb);
-          if (a_rot != 0.f) {
-#pragma unroll
-            for (int v = 0; v < G::VEC; ++v) atomicAdd(dst + v, a_rot * g.v[v]);
-          }
-          a_rot = dpp_f<GDN_DPP_ROR1>(a_rot);
-          jb = dpp_i<GDN_DPP_ROR1>(jb);
         }
       }
       dsi = row16_sum(dsi);
       if (l16 == 0 && slice == 0) d_si[row0 + i] = dsi;
     }
     __syncthreads();
-    {
-      const float4* src = reinterpret_cast<const float4*>(dxl);
-      float4* dst = reinterpret_cast<float4*>(d_xlin + row0 * D);
-      const int nvec = pl.n * D / 4;
+    {   // the tile now holds d_z of this window (row n stays 0)
+      const float4* src = reinterpret_cast<const float4*>(d_z + row0 * D);
+      float4* dst = reinterpret_cast<float4*>(tile);
       for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
-      for (int t = tid; t < pl.n; t += nth) d_sj[row0 + t] = dsj[t];
     }
     __syncthreads();
+
+    // ---- pass 2: per source, over its reverse list
+    for (int j = slot; j < pl.n; j += tpp) {
+      const int len = rlen[j];
+      const uint32_t* rrow = rent + (size_t)j * pl.rpitch;
+      PackB<G::VEC> acc;
+#pragma unroll
+      for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
+      float dsj = 0.f;
+      for (int r0 = 0; r0 < len; r0 += 16) {
+        const int e = r0 + l16;
+        const bool valid = e < len;
+        const uint32_t ent = rrow[valid ? e : 0];
+        const int i = ent >> 16, p = ent & 0xffff;
+        const float a = valid ? al_t[i * pl.pitch + p] : 0.f;
+        dsj += valid ? dpi_t[i * pl.pitch + p] : 0.f;
+        axpy_steps<D>(tile_lane, a, (valid ? i : pl.n) * (D * 4), acc);
+      }
+      stp<G::VEC>(d_xlin + (row0 + j) * D + d0, acc);
+      dsj = row16_sum(dsj);
+      if (l16 == 0 && slice == 0) d_sj[row0 + j] = dsj;
+    }
+    __syncthreads();   // tables and tile are rewritten by the next window
   }
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v) atomicAdd(&dbias[d0 + v], bias_acc.v[v]);
   __syncthreads();
   for (int t = tid; t < D; t += nth) atomicAdd(&d_bias[t], dbias[t]);
+}
+
+// Reverse lists: for source j, the (target i, slot p) pairs with nbr[i][p] == j, in ascending i
+// (a source appears at most once per target).  One block per source; rent[j, rpitch] u32 = i<<16 | p.
+__global__ __launch_bounds__(256) void gdn_graph_reverse_kernel(const uint16_t* __restrict__ nbr,
+                                                                const int32_t* __restrict__ deg, int n,
+                                                                int pitch, int rpitch,
+                                                                uint32_t* __restrict__ rent,
+                                                                int32_t* __restrict__ rlen) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base_s;
+  const int j = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    int found = -1;
+    if (i < n) {
+      const int dg = deg[i];
+      for (int p = 0; p < dg; ++p)
+        if (nbr[(size_t)i * pitch + p] == j) found = p;
+    }
+    const unsigned long long m = __ballot(found >= 0);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int q = 0; q < wv; ++q) off += wave_cnt[q];
+    if (found >= 0) rent[(size_t)j * rpitch + off + before] = ((uint32_t)i << 16) | (uint32_t)found;
+    __syncthreads();
+    if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) rlen[j] = base_s;
 }
 
 // d_lin_w[d,w] += sum_rows d_xlin[row,d] x[row,w];  d_a[2,64] += sum_rows d_s[row] x[row,:];
@@ -279,35 +350,44 @@ int occupancy_grid(K kern, int threads, int lds, int batch) {
 
 }  // namespace
 
+extern "C" int gdn_rev_pitch(int n) { return (n + 15) & ~15; }
+
+extern "C" int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n, int k, uint32_t* rent,
+                                 int32_t* rlen, void* stream) {
+  if (!nbr || !deg || !rent || !rlen || n <= 0 || k <= 0) return GDN_ERR_ARG;
+  if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gdn_graph_reverse_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, nbr, deg, n,
+                     gdn_nbr_pitch(k), gdn_rev_pitch(n), rent, rlen);
+  return gdn_launch_status();
+}
+
 extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
                                       const float* s_i, const float* s_j, const uint16_t* nbr,
-                                      const int32_t* deg, int batch, int n, int d, int k, float* d_xlin,
-                                      float* d_si, float* d_sj, float* d_bias, void* stream) {
-  if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !deg || !d_xlin || !d_si || !d_sj || !d_bias ||
-      batch <= 0 || n <= 0 || k <= 0)
+                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                      void* stream) {
+  if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !rent || !rlen || !d_xlin || !d_si || !d_sj ||
+      !d_bias || batch <= 0 || n <= 0 || k <= 0)
     return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
   BwdPlan pl;
-  pl.n = n; pl.d = d; pl.k = k; pl.batch = batch; pl.pitch = gdn_nbr_pitch(k);
+  pl.n = n; pl.d = d; pl.k = k; pl.batch = batch; pl.pitch = gdn_nbr_pitch(k); pl.rpitch = gdn_rev_pitch(n);
   const int npad = (n + 1 + 3) & ~3;   // +1: the sentinel index n used as list padding
   int off = 0;
-  pl.off_xl = off; off += (n + 1) * d;
-  pl.off_dxl = off; off += (n + 1) * d;
+  pl.off_tile = off; off += (n + 1) * d;
   pl.off_sj = off; off += npad;
-  pl.off_dsj = off; off += npad;
+  pl.off_al = off; off += n * pl.pitch;
+  pl.off_dpi = off; off += n * pl.pitch;
   pl.off_dbias = off; off += d;
-  pl.off_deg = off; off += (npad / 2 + 3) & ~3;
-  pl.off_dal = off; off += 16 * pl.pitch;
-  pl.off_nbr = off; off += n * pl.pitch / 2;
   pl.lds_bytes = off * 4;
-  if (pl.lds_bytes > 160 * 1024) return GDN_ERR_UNSUPPORTED;  // TODO: global-atomic variant for big tiles
+  if (pl.lds_bytes > 160 * 1024) return GDN_ERR_UNSUPPORTED;   // n*d tile + two [n,pitch] tables
   hipStream_t st = (hipStream_t)stream;
 #define GDN_BWD(DD)                                                                                  \
   case DD: {                                                                                         \
     const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD>, 256, pl.lds_bytes, batch);              \
     hipLaunchKernelGGL(gdn_attn_bwd_kernel<DD>, dim3(grid), dim3(256), pl.lds_bytes, st, pl, d_z, xlin, \
-                       alpha, s_i, s_j, nbr, deg, d_xlin, d_si, d_sj, d_bias);                       \
+                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias);                \
   } break;
   switch (d) {
     GDN_BWD(16)

@@ -38,6 +38,19 @@ class SensorGraph:
         self.topk, self.nbr, self.deg, self.cos = topk, nbr, deg, cos
         self.n, self.k = topk.shape
         self.pitch = nbr.shape[1]
+        self._reverse = None
+
+    def reverse(self):
+        """(rent[n, rpitch] u32, rlen[n] i32): per source, the (target << 16 | slot) entries that
+        name it — the backward pass gathers through these.  Built on first use."""
+        if self._reverse is None:
+            rpitch = (self.n + 15) & ~15
+            rent = torch.empty((self.n, rpitch), dtype=torch.int32, device=self.nbr.device)
+            rlen = torch.empty((self.n,), dtype=torch.int32, device=self.nbr.device)
+            _lib.call("gdn_graph_reverse", _ptr(self.nbr), _ptr(self.deg), self.n, self.k, _ptr(rent), _ptr(rlen),
+                      _stream())
+            self._reverse = (rent, rlen)
+        return self._reverse
 
 
 def topk_graph(emb: torch.Tensor, k: int, want_cos: bool = False) -> SensorGraph:
@@ -144,8 +157,9 @@ def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: in
     d_si = torch.empty((bn,), dtype=torch.float32, device=d_z.device)
     d_sj = torch.empty_like(d_si)
     d_bias = torch.zeros((d,), dtype=torch.float32, device=d_z.device)
+    rent, rlen = graph.reverse()
     _lib.call("gdn_attn_aggregate_bwd", _ptr(d_z), _ptr(_chk(xlin)), _ptr(_chk(alpha)), _ptr(_chk(s_i)),
-              _ptr(_chk(s_j)), _ptr(graph.nbr), _ptr(graph.deg), batch, n, d, graph.k,
+              _ptr(_chk(s_j)), _ptr(graph.nbr), _ptr(rent), _ptr(rlen), batch, n, d, graph.k,
               _ptr(d_xlin), _ptr(d_si), _ptr(d_sj), _ptr(d_bias), _stream())
     return d_xlin, d_si, d_sj, d_bias
 

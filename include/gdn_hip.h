@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 2
+#define GDN_ABI_VERSION 3
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -118,14 +118,22 @@ int gdn_forward_fused(const float* x, const float* lin_w, const float* node_term
  * Gradients of gdn_attn_aggregate_fwd and gdn_project_fwd; the autograd graph of
  * `loss.backward()` at train.py:72 restricted to the GraphLayer.  No gradient flows into
  * the neighbour lists (the graph is built from a detached embedding, models/GDN.py:145).
- *   d_xlin[BN,d]  (+)= grads from both the message term and nothing else;
+ *   d_xlin[BN,d]  gradient of the message term (gathered through the reverse lists: no
+ *                 scatter atomics, bitwise reproducible);
  *   d_si, d_sj    grads of the per-node scalars; d_bias[d] accumulated with atomics
  *                 (caller zeroes d_bias first).                                         */
 int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
                            const float* s_i, const float* s_j,
-                           const uint16_t* nbr, const int32_t* deg,
+                           const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
                            int batch, int n, int d, int k,
                            float* d_xlin, float* d_si, float* d_sj, float* d_bias, void* stream);
+
+/* Reverse neighbour lists for the backward gather: rent[n, gdn_rev_pitch(n)] u32 holds, for
+ * source j, (target << 16 | slot) of every list entry that names j, ascending target;
+ * rlen[n] their counts.  Built once per graph.                                           */
+int gdn_rev_pitch(int n);
+int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n, int k,
+                      uint32_t* rent, int32_t* rlen, void* stream);
 
 /* x[BN,w], d_xlin[BN,d], d_si/d_sj[BN] -> d_lin_w[d,w] (direct term), d_a[2,64]
  * (grads of a_i, a_j), d_c[2,n] (grads of c_i, c_j); all accumulated with atomics into
