@@ -276,26 +276,30 @@ __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
   for (int t = tid; t < D * wp + 128 + 2 * n; t += nth) dw[t] = 0.f;
   __syncthreads();
 
-  for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-    const size_t row0 = (size_t)b * n;
-    const float* xg = x + row0 * w;
-    for (int t = tid; t < n * wp; t += nth) {
-      const int r = t / wp, c = t - r * wp;
-      xs[t] = c < w ? xg[(size_t)r * w + c] : 0.f;
-    }
-    for (int t = tid; t < n; t += nth) {
-      dc[t] += d_si[row0 + t];
-      dc[n + t] += d_sj[row0 + t];
-    }
-    __syncthreads();
-    for (int wc = 0; wc < nch; ++wc) {
-      float acc[G::VEC][WCH];
+  // accumulators live in registers across ALL windows of this workgroup and are flushed once per
+  // W-chunk (flushing per window cost 16k ds_add_f32 per window)
+  for (int wc = 0; wc < nch; ++wc) {
+    float acc[G::VEC][WCH];
 #pragma unroll
-      for (int v = 0; v < G::VEC; ++v)
+    for (int v = 0; v < G::VEC; ++v)
 #pragma unroll
-        for (int c = 0; c < WCH; ++c) acc[v][c] = 0.f;
-      float ai = 0.f, aj = 0.f;
-      const bool ahas = l16 < WCH;
+      for (int c = 0; c < WCH; ++c) acc[v][c] = 0.f;
+    float ai = 0.f, aj = 0.f;
+    const bool ahas = l16 < WCH;
+    for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+      const size_t row0 = (size_t)b * n;
+      const float* xg = x + row0 * w;
+      for (int t = tid; t < n * wp; t += nth) {
+        const int r = t / wp, c = t - r * wp;
+        xs[t] = c < w ? xg[(size_t)r * w + c] : 0.f;
+      }
+      if (wc == 0) {
+        for (int t = tid; t < n; t += nth) {
+          dc[t] += d_si[row0 + t];
+          dc[n + t] += d_sj[row0 + t];
+        }
+      }
+      __syncthreads();
       for (int row = slot; row < n; row += tpp) {
         const float* xrow = xs + (size_t)row * wp + wc * WCH;
         float xr[WCH];
@@ -315,17 +319,18 @@ __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
           aj = fmaf(d_sj[row0 + row], xv, aj);
         }
       }
-#pragma unroll
-      for (int v = 0; v < G::VEC; ++v)
-#pragma unroll
-        for (int c = 0; c < WCH; ++c) atomicAdd(&dw[(size_t)(d0 + v) * wp + wc * WCH + c], acc[v][c]);
-      if (slice == 0 && ahas) {
-        atomicAdd(&da[wc * WCH + l16], ai);
-        atomicAdd(&da[64 + wc * WCH + l16], aj);
-      }
+      __syncthreads();   // the x tile is restaged for the next window
     }
-    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < G::VEC; ++v)
+#pragma unroll
+      for (int c = 0; c < WCH; ++c) atomicAdd(&dw[(size_t)(d0 + v) * wp + wc * WCH + c], acc[v][c]);
+    if (slice == 0 && ahas) {
+      atomicAdd(&da[wc * WCH + l16], ai);
+      atomicAdd(&da[64 + wc * WCH + l16], aj);
+    }
   }
+  __syncthreads();
   // one flush per workgroup
   for (int t = tid; t < D * wp; t += nth) {
     const int r = t / wp, c = t - r * wp;
