@@ -269,7 +269,7 @@ def main():
                        "parallelism": f"windows sharded over {world} rank(s); scoring all-to-all by sensor"
                        if world > 1 else "single GPU"},
         }
-    if world == 1:
+    if rank == 0:
         pred = ev.pred
         sweep = []
         for b in sorted({batch, launch_batch, t}):
@@ -279,7 +279,7 @@ def main():
         result["roofline_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
                                      "launch_us": r["launch_us"]} for r in sweep]
         result["roofline_fused"] = fused_roofline(model, x, pred, launch_batch, launches=max(12, min(64, 65536 // launch_batch)))
-        if args.coalesce > 1:      # transparency: the same step with one launch per logical minibatch
+        if args.coalesce > 1 and world == 1:      # transparency: the same step with one launch per logical minibatch
             ev1 = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams)
             for _ in range(args.warmup):
                 ev1.step()
@@ -289,6 +289,20 @@ def main():
                 ev1.step()
             torch.cuda.synchronize()
             result["value_per_batch_launches"] = round(t * args.steps / (time.perf_counter() - t1), 1)
+    if rank == 0 and world == 1:
+        # the same step with the windows built in-kernel from the raw [N, T+W] series
+        raw = torch.rand((N_SENSORS, t + WINDOW), generator=torch.Generator().manual_seed(7)).to(device)
+        ev2 = harness.SeriesEvaluator(model, None, raw[:, WINDOW:].t().contiguous(), batch=batch,
+                                      use_graph=not args.no_graph, streams=args.streams, coalesce=args.coalesce,
+                                      series=raw)
+        for _ in range(args.warmup):
+            ev2.step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            ev2.step()
+        torch.cuda.synchronize()
+        result["value_windows_from_raw_series"] = round(t * args.steps / (time.perf_counter() - t2), 1)
         if not args.skip_cpu:
             result["cpu_baseline"] = cpu_baseline(params)
     if dist is not None:

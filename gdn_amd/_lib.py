@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdn_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "gdn_attn_aggregate_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_head_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],
+    "gdn_forward_fused_series": [_p, _c_int, _c_int] + [_p] * 10 + [_c_int] * 5 + [_p, _p],
     "gdn_attn_aggregate_bwd": [_p] * 8 + [_c_int] * 4 + [_p] * 5,
     "gdn_rev_pitch": [_c_int],
     "gdn_graph_reverse": [_p, _p, _c_int, _c_int, _p, _p, _p],

@@ -117,7 +117,9 @@ enum { MODE_PROJECT = 0, MODE_ATTN = 1, MODE_FUSED = 2 };
 
 struct Args {
   // inputs
-  const float* x;           // [B, n, w]
+  const float* x;           // [B, n, w], or the raw series [n, series_len] when series_len > 0
+  int series_len;           // > 0: window b = series[:, series_first + b : series_first + b + w]
+  int series_first;
   const float* lin_w;       // [d, w]
   const float* node_terms;  // [a_i(64) | a_j(64) | c_i(n) | c_j(n)]
   const float* xlin_in;     // [BN, d]  (MODE_ATTN)
@@ -560,11 +562,21 @@ struct XFlat {
   float v[XU];
 };
 
+// Element t of a window is src[(t / w) * row_stride + t % w]: row_stride = w for materialised
+// windows x[b] (src = x + b*n*w), row_stride = series_len when the window is read straight from the
+// raw [n, series_len] series (src = series + first + b; reference datasets/TimeDataset.py:46-49
+// builds x[b] = data[:, b : b+w] on the host, a w-fold redundant copy — neighbouring windows share
+// all but one column, so the series is fetched from HBM once).  One code path, no branch.
 template <int XU>
-__device__ __forceinline__ void xflat_load(const float* xg, int cnt, XFlat<XU>& r) {
+__device__ __forceinline__ void xflat_load(const float* src, int row_stride, int cnt, int w, float inv_w,
+                                           XFlat<XU>& r) {
 #pragma unroll
-  for (int u = 0; u < XU; ++u)   // unconditional, clamped: stays in registers
-    r.v[u] = xg[min((int)threadIdx.x + u * (int)blockDim.x, cnt - 1)];
+  for (int u = 0; u < XU; ++u) {   // unconditional, clamped: stays in registers
+    const int t = min((int)threadIdx.x + u * (int)blockDim.x, cnt - 1);
+    const int row = (int)((t + 0.5f) * inv_w);   // exact for t < 2^16, w <= 64
+    // 32-bit, window-invariant offset from a wave-uniform base: one VGPR per element
+    r.v[u] = src[(unsigned int)(row * row_stride + (t - row * w))];
+  }
 }
 
 template <int XU>
@@ -660,14 +672,18 @@ __device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, 
   const int cnt = pl.n * pl.w;
   const float inv_w = 1.0f / (float)pl.w;
   XFlat<XU> xr;
-  xflat_load<XU>(a.x + (size_t)blockIdx.x * cnt, cnt, xr);
+  const int row_stride = a.series_len > 0 ? a.series_len : pl.w;
+  const size_t win_stride = a.series_len > 0 ? 1 : (size_t)cnt;   // distance between windows b, b+1
+  const float* x0 = a.x + (a.series_len > 0 ? a.series_first : 0);
+  auto load_window = [&](int bb) { xflat_load<XU>(x0 + (size_t)bb * win_stride, row_stride, cnt, pl.w, inv_w, xr); };
+  load_window(blockIdx.x);
   __syncthreads();   // zero fill done before the first store
   xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
   __syncthreads();
   // two barriers per window: [loads of b+1 | s + MFMA of b] B [aggregate b | store x of b+1] C
   for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
     const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round: harmless re-read
-    xflat_load<XU>(a.x + (size_t)nb * cnt, cnt, xr);        // lands under the math
+    load_window(nb);                                        // lands under the math
     project_mfma<D, MODE, WPM>(pl, a, smem, b, wb);
     __syncthreads();                                        // B: tile + scalars ready, x tile free
     if constexpr (MODE == MODE_FUSED) aggregate_window<D, MODE, LST>(pl, a, smem, b);
@@ -1132,6 +1148,30 @@ extern "C" int gdn_forward_fused(const float* x, const float* lin_w, const float
   a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;
   a.out_w = out_w; a.out_b = out_b; a.out = out;
   if (pl.nslices > 1 &&   // the slices add their partial head outputs into `out`
+      hipMemsetAsync(out, 0, (size_t)batch * n * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return GDN_ERR_LAUNCH;
+  return dispatch_window<MODE_FUSED>(pl, a, threads, (hipStream_t)stream);
+}
+
+extern "C" int gdn_forward_fused_series(const float* series, int series_len, int first, const float* lin_w,
+                                        const float* node_terms, const uint16_t* nbr, const int32_t* deg,
+                                        const float* gnn_bias, const float* emb, const float* bn1_affine,
+                                        const float* bn2_affine, const float* out_w, const float* out_b,
+                                        int batch, int n, int w, int d, int k, float* out, void* stream) {
+  if (!series || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine ||
+      !bn2_affine || !out_w || !out_b || !out || series_len <= 0 || first < 0)
+    return GDN_ERR_ARG;
+  if ((long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;   // last window must fit
+  Plan pl; int threads;
+  const int rc = make_plan(MODE_FUSED, batch, n, w, d, k, &pl, &threads);
+  if (rc != GDN_OK) return rc;
+  if (!pl.mfma) return GDN_ERR_UNSUPPORTED;   // series addressing lives in the MFMA-projection variants
+  Args a = {};
+  a.x = series; a.series_len = series_len; a.series_first = first;
+  a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.deg = deg;
+  a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;
+  a.out_w = out_w; a.out_b = out_b; a.out = out;
+  if (pl.nslices > 1 &&
       hipMemsetAsync(out, 0, (size_t)batch * n * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return GDN_ERR_LAUNCH;
   return dispatch_window<MODE_FUSED>(pl, a, threads, (hipStream_t)stream);

@@ -213,16 +213,21 @@ class SeriesEvaluator:
     :131-139), with nothing leaving the device.  With `use_graph=True` the launches of a step
     are captured once in a HIP graph and replayed."""
 
-    def __init__(self, model, x_all: torch.Tensor, y_all: torch.Tensor, batch: int, use_graph: bool = True,
-                 want_scores: bool = False, streams: int = 4, coalesce: int = 1):
+    def __init__(self, model, x_all: torch.Tensor | None, y_all: torch.Tensor, batch: int, use_graph: bool = True,
+                 want_scores: bool = False, streams: int = 4, coalesce: int = 1,
+                 series: torch.Tensor | None = None):
         """`batch` = the logical minibatch of the reference's loader; `coalesce` consecutive batches
         (contiguous in the resident series) go out as ONE launch — eval results do not depend on the
         minibatch size, and launches of a few thousand windows amortise the per-workgroup prologue."""
-        assert x_all.is_cuda and y_all.is_cuda
+        # `series` [N, T_raw] (datasets/TimeDataset.py:42 layout) replaces x_all: window t is
+        # series[:, t : t+W], built inside the kernel — no [T, N, W] tensor (SURVEY §8f-1)
+        assert (x_all is None) != (series is None), "give either the window tensor or the raw series"
+        assert y_all.is_cuda and (x_all if x_all is not None else series).is_cuda
+        self.series = series
         self.model, self.x, self.y, self.batch = model.eval(), x_all, y_all, batch * max(1, coalesce)
         self.logical_batch, self.coalesce = batch, max(1, coalesce)
         self.t, self.n = y_all.shape
-        dev = x_all.device
+        dev = y_all.device
         self.pred = torch.empty((self.t, self.n), dtype=torch.float32, device=dev)
         self.ws = ops.score_workspace(self.t, self.n, dev)
         self.med_iqr = torch.empty((self.n, 2), dtype=torch.float64, device=dev)
@@ -239,9 +244,15 @@ class SeriesEvaluator:
     def _launch_forward(self):
         m = self.model
         spans = [(s, min(self.t, s + self.batch)) for s in range(0, self.t, self.batch)]
+        if self.series is not None:
+            def launch(s, e):
+                m.forward_series(self.series, s, e - s, out=self.pred[s:e])
+        else:
+            def launch(s, e):
+                m.forward_into(self.x[s:e], self.pred[s:e])
         if len(self.side) < 2:
             for s, e in spans:
-                m.forward_into(self.x[s:e], self.pred[s:e])
+                launch(s, e)
             return
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
@@ -250,7 +261,7 @@ class SeriesEvaluator:
             st.wait_event(fork)
         for i, (s, e) in enumerate(spans):
             with torch.cuda.stream(self.side[i % len(self.side)]):
-                m.forward_into(self.x[s:e], self.pred[s:e])
+                launch(s, e)
         for st in self.side:
             join = torch.cuda.Event()
             join.record(st)
@@ -269,6 +280,14 @@ class SeriesEvaluator:
         self._launch_forward()
         self._launch_score()
 
+    def _fresh(self):
+        """Captured graphs bake in the pointers of the model's folded constants: drop them when a
+        parameter changed since the capture."""
+        key = self.model._constants().key
+        if key != getattr(self, "_graph_key", None):
+            self.graph = self.fgraph = None
+            self._graph_key = key
+
     def _capture(self, fn):
         self.model._constants()                      # build graph/constants outside the capture
         fn()                                         # warm-up (occupancy queries, attributes)
@@ -283,6 +302,7 @@ class SeriesEvaluator:
         if not self.use_graph:
             self._launch_forward()
             return self.pred
+        self._fresh()
         if self.fgraph is None:
             self.fgraph = self._capture(self._launch_forward)
         self.fgraph.replay()
@@ -292,6 +312,7 @@ class SeriesEvaluator:
         if not self.use_graph:
             self._launch_all()
             return self.anomaly
+        self._fresh()
         if self.graph is None:
             self.graph = self._capture(self._launch_all)
         self.graph.replay()

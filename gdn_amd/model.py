@@ -296,6 +296,20 @@ class GDN(nn.Module):
         return ops.forward_fused(data, gnn.lin.weight, c.terms, c.graph, gnn.bias, self.embedding.weight,
                                  c.bn1, c.bn2, lin.weight, lin.bias, out=out)
 
+    def forward_series(self, series, first: int, batch: int, out=None):
+        """Eval forward of `batch` consecutive stride-1 windows taken directly from the raw series
+        [node_num, T] (the layout `TimeDataset` slices, datasets/TimeDataset.py:42-49): window b is
+        series[:, first+b : first+b+W] and predicts column first+b+W.  No [T, N, W] tensor exists."""
+        if self.training or self.out_layer_num != 1:
+            raise RuntimeError("forward_series is the eval / out_layer_num == 1 fast path")
+        c = self._constants()
+        gnn = self.gnn_layers[0].gnn
+        lin = self.out_layer.mlp[0]
+        self.learned_graph = c.graph.topk
+        return ops.forward_fused_series(series, first, batch, gnn.lin.weight.shape[1], gnn.lin.weight, c.terms,
+                                        c.graph, gnn.bias, self.embedding.weight, c.bn1, c.bn2, lin.weight,
+                                        lin.bias, out=out)
+
     def _dense_attention(self, x, c, batch):
         gnn = self.gnn_layers[0].gnn
         xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)

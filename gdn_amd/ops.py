@@ -148,6 +148,23 @@ def forward_fused(x, lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine
     return out
 
 
+def forward_fused_series(series, first: int, batch: int, w: int, lin_w, terms, graph: SensorGraph, gnn_bias, emb,
+                         bn1_affine, bn2_affine, out_w, out_b, out: torch.Tensor | None = None):
+    """Fused eval forward of `batch` stride-1 windows read straight from series[n, T]
+    (datasets/TimeDataset.py:46-49 without the w-fold copy)."""
+    series = _chk(series, name="series")
+    n, t_len = series.shape
+    lin_w = _chk(lin_w.detach(), name="lin.weight")
+    d = lin_w.shape[0]
+    if out is None:
+        out = torch.empty((batch, n), dtype=torch.float32, device=series.device)
+    _lib.call("gdn_forward_fused_series", _ptr(series), t_len, first, _ptr(lin_w), _ptr(terms), _ptr(graph.nbr),
+              _ptr(graph.deg), _ptr(_chk(gnn_bias.detach())), _ptr(_chk(emb.detach())), _ptr(bn1_affine),
+              _ptr(bn2_affine), _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
+              batch, n, w, d, graph.k, _ptr(out), _stream())
+    return out
+
+
 def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: int):
     """Gradient of attn_aggregate_fwd w.r.t. xlin, s_i, s_j and bias."""
     d_z = _chk(d_z, name="d_z")

@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 3
+#define GDN_ABI_VERSION 4
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -113,6 +113,17 @@ int gdn_forward_fused(const float* x, const float* lin_w, const float* node_term
                       const float* emb, const float* bn1_affine, const float* bn2_affine,
                       const float* out_w, const float* out_b,
                       int batch, int n, int w, int d, int k, float* out, void* stream);
+
+/* Same forward fed from the RAW series instead of materialised windows: series[n, series_len]
+ * fp32 (the [node, time] layout of datasets/TimeDataset.py:42); window b of the launch is
+ * series[:, first+b : first+b+w] (TimeDataset.py:46-49 with stride 1, the test-mode loop), its
+ * target column is first+b+w.  Requires first + batch - 1 + w <= series_len.  Needs d >= 32 and
+ * w <= 32 (the matrix-core projection variants); otherwise GDN_ERR_UNSUPPORTED.          */
+int gdn_forward_fused_series(const float* series, int series_len, int first, const float* lin_w,
+                             const float* node_terms, const uint16_t* nbr, const int32_t* deg,
+                             const float* gnn_bias, const float* emb, const float* bn1_affine,
+                             const float* bn2_affine, const float* out_w, const float* out_b,
+                             int batch, int n, int w, int d, int k, float* out, void* stream);
 
 /* ---- backward (training) -------------------------------------------------------------
  * Gradients of gdn_attn_aggregate_fwd and gdn_project_fwd; the autograd graph of

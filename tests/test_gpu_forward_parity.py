@@ -171,3 +171,19 @@ def test_zero_norm_embedding_row_reproduces_reference_nan_behaviour(gpu_device):
             continue            # an all-NaN row: torch's pick among equal keys is unspecified
         assert got[i, 0] == 7   # the NaN column ranks first
         assert got[i].tolist() == ref[i].tolist()
+
+
+@pytest.mark.parametrize("n,w,k,d,t_len", [(127, 15, 30, 64, 700), (27, 5, 5, 64, 300), (40, 30, 16, 128, 200)])
+def test_windows_read_from_the_raw_series_equal_materialised_windows(n, w, k, d, t_len, gpu_device):
+    """x[b] = series[:, b : b+w] (datasets/TimeDataset.py:46-49, test mode) built inside
+    the kernel must give bit-identical predictions to the host-built [T', N, W] tensor."""
+    model = random_params(n, w, k, d, seed=11).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(2)
+    series = torch.rand((n, t_len), generator=g).to(gpu_device)
+    windows = torch.stack([series[:, i - w:i] for i in range(w, t_len)]).contiguous()    # TimeDataset.process
+    with torch.no_grad():
+        want = model(windows, None)
+    got = model.forward_series(series, 0, t_len - w)
+    assert torch.equal(got, want)
+    part = model.forward_series(series, 37, 101)
+    assert torch.equal(part, want[37:138])

@@ -120,3 +120,37 @@ def test_sharded_smoothing_with_halo_equals_whole_series(t, n, cuts, gpu_device)
         parts.append(an)
         assert torch.equal(sc.max(dim=0).values, an)
     assert torch.equal(torch.cat(parts), whole)
+
+
+def test_series_evaluator_from_raw_series_equals_window_tensor(gpu_device):
+    """SURVEY §8f-1 through the evaluator: windows built in-kernel from the raw [N, T] series give the
+    same predictions and anomaly scores as the host-built [T', N, W] tensor."""
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    n, w = 127, 15
+    model = random_params(n, w, 30, 64, seed=5).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(4)
+    raw = torch.rand((n, 1200), generator=g).to(gpu_device)
+    x = torch.stack([raw[:, i - w:i] for i in range(w, raw.shape[1])]).contiguous()     # TimeDataset.process
+    y = raw[:, w:].t().contiguous()
+    a = harness.SeriesEvaluator(model, x, y, batch=256, coalesce=2, use_graph=True)
+    b = harness.SeriesEvaluator(model, None, y, batch=256, coalesce=2, use_graph=True, series=raw)
+    ra, rb = a.step().clone(), b.step().clone()
+    assert torch.equal(a.pred, b.pred) and torch.equal(ra, rb)
+
+
+def test_captured_graph_is_dropped_when_a_parameter_changes(gpu_device):
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    model = random_params(27, 5, 5, 64, seed=9).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand((300, 27, 5), generator=g).to(gpu_device)
+    y = torch.rand((300, 27), generator=g).to(gpu_device)
+    ev = harness.SeriesEvaluator(model, x, y, batch=100, use_graph=True)
+    ev.step()
+    before = ev.pred.clone()
+    with torch.no_grad():
+        model.out_layer.mlp[0].bias.add_(1.0)          # in-place update, as an optimizer would do
+    ev.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(ev.pred, before + 1.0, atol=1e-6)
