@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 
 def _glorot(t: torch.Tensor) -> None:
@@ -177,7 +177,7 @@ class OutLayer(nn.Module):
 
 
 class _EvalConstants:
-    __slots__ = ("key", "graph", "terms", "bn1", "bn2")
+    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args")
 
 
 class GDN(nn.Module):
@@ -213,9 +213,18 @@ class GDN(nn.Module):
         nn.init.kaiming_uniform_(self.embedding.weight, a=math.sqrt(5))
 
     # ------------------------------------------------------------------ constants
+    def _apply(self, fn, *args, **kwargs):
+        # .to(device) / .float() replace the parameter storage: forget cached tensors and constants
+        self._key_tensors = None
+        self._consts = None
+        return super()._apply(fn, *args, **kwargs)
+
     def _param_key(self):
-        ps = [self.embedding.weight, *self.gnn_layers[0].parameters(), *self.bn_outlayer_in.parameters(),
-              *self.gnn_layers[0].bn.buffers(), *self.bn_outlayer_in.buffers()]
+        ps = getattr(self, "_key_tensors", None)
+        if ps is None:
+            ps = [self.embedding.weight, *self.gnn_layers[0].parameters(), *self.bn_outlayer_in.parameters(),
+                  *self.gnn_layers[0].bn.buffers(), *self.bn_outlayer_in.buffers(), *self.out_layer.parameters()]
+            self._key_tensors = ps
         inj = None if self.injected_graph is None else (self.injected_graph.data_ptr(), self.injected_graph._version)
         return tuple((p.data_ptr(), p._version) for p in ps) + (self.training, inj)
 
@@ -235,11 +244,32 @@ class GDN(nn.Module):
             c.graph = ops.topk_graph(emb, self.topk)                       # GDN.py:145-159
         c.terms = ops.node_terms(gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i, gnn.att_em_j, emb)
         c.bn1 = c.bn2 = None
+        c.fused_args = None
         if not self.training:
             c.bn1 = ops.bn_fold(self.gnn_layers[0].bn)
             c.bn2 = ops.bn_fold(self.bn_outlayer_in)
+            if self.out_layer_num == 1:
+                # raw argument tuple of gdn_forward_fused (validated once here, not per call)
+                lin = self.out_layer.mlp[0]
+                ts = (gnn.lin.weight, c.terms, c.graph.nbr, c.graph.deg, gnn.bias, emb, c.bn1, c.bn2,
+                      lin.weight, lin.bias)
+                assert all(t.is_cuda and t.is_contiguous() for t in ts)
+                d, w = gnn.lin.weight.shape
+                c.fused_args = (tuple(t.data_ptr() for t in ts), emb.shape[0], w, d, c.graph.k)
         self._consts = c
         return c
+
+    def _launch_fused(self, x, c, out):
+        """One ctypes call; every argument except x / out comes from the constants cache."""
+        if not x.is_cuda:
+            raise _lib.GdnHipError(f"input is on {x.device}: gdn_amd needs a HIP device (no CPU fallback)")
+        ptrs, n, w, d, k = c.fused_args
+        b = x.shape[0]
+        if x.shape[1] != n or x.shape[2] != w:
+            raise ValueError(f"expected data of shape [B, {n}, {w}], got {tuple(x.shape)}")
+        _lib.call("gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        return out
 
     # ------------------------------------------------------------------ forward
     def forward(self, data, org_edge_index=None):
@@ -256,9 +286,8 @@ class GDN(nn.Module):
 
         if not self.training:
             if self.out_layer_num == 1:
-                lin = self.out_layer.mlp[0]
-                out = ops.forward_fused(x, gnn.lin.weight, c.terms, c.graph, gnn.bias, emb, c.bn1, c.bn2,
-                                        lin.weight, lin.bias)
+                out = torch.empty((batch, node_num), dtype=torch.float32, device=x.device)
+                self._launch_fused(x, c, out)
                 layer._set_dense(lambda: self._dense_attention(x, c, batch))
                 return out
             xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
@@ -290,11 +319,10 @@ class GDN(nn.Module):
         if self.training or self.out_layer_num != 1:
             raise RuntimeError("forward_into is the eval / out_layer_num == 1 fast path")
         c = self._constants()
-        gnn = self.gnn_layers[0].gnn
-        lin = self.out_layer.mlp[0]
         self.learned_graph = c.graph.topk
-        return ops.forward_fused(data, gnn.lin.weight, c.terms, c.graph, gnn.bias, self.embedding.weight,
-                                 c.bn1, c.bn2, lin.weight, lin.bias, out=out)
+        if data.dtype != torch.float32 or not data.is_contiguous():
+            data = data.float().contiguous()
+        return self._launch_fused(data, c, out)
 
     def forward_series(self, series, first: int, batch: int, out=None):
         """Eval forward of `batch` consecutive stride-1 windows taken directly from the raw series
