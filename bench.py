@@ -189,6 +189,21 @@ def cpu_baseline(params, budget_s=12.0):
 
 
 def main():
+    # stdout carries exactly one JSON line: RCCL prints a version banner to stdout when the first
+    # communicator is created, so everything else goes to stderr until the result is ready
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        result = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -200,6 +215,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="side streams the forward launches rotate over")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="1 rank, but run the N>1 step (RCCL process group, all-to-all scoring exchange)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,8 +227,10 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or args.rehearse_dist:
         import torch.distributed as dist
+        if args.rehearse_dist and "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
         dist.init_process_group("nccl", device_id=device)
 
     from gdn_amd import harness
@@ -224,14 +243,14 @@ def main():
 
     ev = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams,
                                  coalesce=args.coalesce)
-    if world == 1:
+    if world == 1 and not args.rehearse_dist:
         step = ev.step
     else:
         total = t * world
 
         def step():
             ev.forward_only()
-            return harness.distributed_anomaly(ev.pred, y, total)
+            return harness.distributed_anomaly(ev.pred, y, total, rehearse=args.rehearse_dist)
 
     for _ in range(args.warmup):
         step()
@@ -308,8 +327,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+    return result if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdn_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -32,6 +32,9 @@ SIGNATURES = {
     "gdn_graph_reverse": [_p, _p, _c_int, _c_int, _p, _p, _p],
     "gdn_project_bwd": [_p] * 4 + [_c_int] * 4 + [_p] * 4,
     "gdn_score_workspace_bytes": [_c_int, _c_int],
+    "gdn_score_select_workspace_bytes": [_c_int, _c_int, _c_int],
+    "gdn_score_keys": [_p, _p, _c_int, _c_int, _c_int, _p, _p],
+    "gdn_score_select": [_p, _c_int, _c_int, _c_int, ctypes.c_longlong, _p, _p, _p],
     "gdn_score_quantiles": [_p, _p, _c_int, _c_int, _p, _p, _p],
     "gdn_score_smooth_max": [_p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p, _p, _p],
 }
@@ -60,7 +63,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_longlong if name == "gdn_score_workspace_bytes" else _c_int
+        fn.restype = ctypes.c_longlong if name.endswith("workspace_bytes") else _c_int
     if lib.gdn_abi_version() != ABI_VERSION:
         raise GdnHipError(f"ABI mismatch: library {lib.gdn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

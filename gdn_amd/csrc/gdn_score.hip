@@ -16,11 +16,15 @@ struct SelectArgs {
   int median_pair;   // 1: t even, median = mean of two middle values
 };
 
-// delta[s][tick] = |pred[tick][s] - gt[tick][s]| in float64, transposed through LDS so that both
-// the fp32 reads (along sensors) and the fp64 writes (along ticks) are coalesced.
-__global__ __launch_bounds__(256) void score_delta_kernel(const float* __restrict__ pred,
-                                                          const float* __restrict__ gt, int t, int n,
-                                                          double* __restrict__ ws) {
+// keys[s][tick] = |pred[tick][s] - gt[tick][s]| in float64 (bit pattern = radix key), transposed
+// through LDS so that both the fp32 reads (along sensors) and the fp64 writes (along ticks) are
+// coalesced.  Row pitch >= t; slots t..pitch-1 get the FILLER pattern (all ones: larger than every real
+// key, never counted).
+constexpr unsigned long long FILLER = ~0ull;
+
+__global__ __launch_bounds__(256) void score_keys_kernel(const float* __restrict__ pred,
+                                                         const float* __restrict__ gt, int t, int n, int pitch,
+                                                         double* __restrict__ keys) {
   __shared__ double tile[64][65];
   const int t0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -34,20 +38,27 @@ __global__ __launch_bounds__(256) void score_delta_kernel(const float* __restric
   __syncthreads();
   for (int r = wv; r < 64; r += 4) {
     const int s = s0 + r, tick = t0 + lane;
-    if (s < n && tick < t) ws[(size_t)s * t + tick] = tile[lane][r];
+    if (s < n && tick < pitch)
+      keys[(size_t)s * pitch + tick] = tick < t ? tile[lane][r] : __longlong_as_double((long long)FILLER);
   }
 }
 
 // ------------------------------------------------------------------ radix select
-// Exact order statistics by an MSB-first 8-bit radix select of NQ ranks per sensor over the sensor's t
-// keys (non-negative doubles order like their bit patterns), spread over the whole chip: one launch per
-// digit, grid =
-// (key slices of 2048, sensors).  A block keeps its <= 2048 keys in registers (8 per thread),
-// histograms the current digit of the keys that still match some rank's prefix in LDS, adds its
-// non-empty bins to the sensor's global histogram, and takes a ticket; the LAST block of a sensor
-// (ticket == slices-1, no spinning anywhere) locates every rank's bin and extends the prefixes for
-// the next launch.  From the third digit on, the matching keys are compacted into a second buffer,
-// so later launches read a few hundred keys per sensor instead of all t.
+// Exact order statistics by an MSB-first 8-bit radix select of NQ ranks per sensor (non-negative
+// doubles order like their bit patterns), spread over the whole chip.
+//
+// Input layout: keys[blocks][n][pitch] — `blocks` row blocks as they arrive from `blocks` ranks in
+// the multi-GPU exchange (one block, pitch = t, on a single GPU); sensor s owns blocks*pitch SLOTS,
+// of which `total` hold real keys and the rest the FILLER.  The input is never written.
+//
+// Digits 0-1 (the exponent bytes) and 2: one launch per digit, grid = (2048-slot slices, sensors);
+// a block keeps its slice in registers (8 keys per thread), histograms the digit of the keys that
+// still match some rank's prefix in LDS (a wave landing in one bin adds 64 at once), adds its
+// non-empty bins to the sensor's global histogram and takes a ticket; the LAST block of a sensor
+// (no spinning, no fences: every consumed value is an agent-scope atomic) locates every rank's bin
+// and extends the prefixes for the next launch.  The digit-2 launch also compacts the matching keys
+// (normally a few percent) into the workspace; digit 3 runs on those, and one single-block finisher
+// launch per sensor does digits 4-7.
 constexpr int SLICE = 2048;
 
 struct SelState {
@@ -56,14 +67,18 @@ struct SelState {
   int rep[NQ];
   unsigned int hist[NQ][256];
   unsigned int arrive;
-  unsigned int cnt_in;    // keys the next pass reads
-  unsigned int cnt_out;   // survivors written by the running pass
-  unsigned int src;       // buffer the next pass reads: 0 = A, 1 = B
+  unsigned int cnt_b;     // keys compacted into the workspace buffer
+  unsigned int pad0, pad1;
 };
 
-__global__ void select_init_kernel(SelState* __restrict__ state, int n, int t, const SelectArgs sa) {
-  const int s = blockIdx.x;
-  SelState& st = state[s];
+struct KeyLayout {
+  const unsigned long long* keys;   // [blocks][n][pitch]
+  unsigned long long* bufb;         // [n][blocks*pitch] compacted survivors
+  int blocks, n, pitch;
+};
+
+__global__ void select_init_kernel(SelState* __restrict__ state, const SelectArgs sa) {
+  SelState& st = state[blockIdx.x];
   for (int i = threadIdx.x; i < NQ * 256; i += blockDim.x) (&st.hist[0][0])[i] = 0u;
   if (threadIdx.x < NQ) {
     st.prefix[threadIdx.x] = 0ull;
@@ -72,26 +87,70 @@ __global__ void select_init_kernel(SelState* __restrict__ state, int n, int t, c
   }
   if (threadIdx.x == 0) {
     st.arrive = 0u;
-    st.cnt_in = (unsigned int)t;
-    st.cnt_out = 0u;
-    st.src = 0u;
+    st.cnt_b = 0u;
   }
 }
 
-template <bool COMPACT>
-__global__ __launch_bounds__(256) void select_pass_kernel(unsigned long long* __restrict__ bufA,
-                                                          unsigned long long* __restrict__ bufB,
-                                                          SelState* __restrict__ state, int t, int pass,
-                                                          const SelectArgs sa, double* __restrict__ med_iqr) {
+// wave q's lanes find the bin of rank q in a 256-bin histogram; returns through npf / nrem
+__device__ __forceinline__ void locate_bin(const unsigned int* h, int left0, unsigned long long pf, int shift,
+                                           int lane, unsigned long long* npf, int* nrem) {
+  const uint4 c4 = *reinterpret_cast<const uint4*>(h + 4 * lane);
+  const int mine = (int)(c4.x + c4.y + c4.z + c4.w);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  const int excl = incl - mine;
+  if (left0 >= excl && left0 < incl) {
+    int left = left0 - excl, bin = 0;
+    const int c[4] = {(int)c4.x, (int)c4.y, (int)c4.z, (int)c4.w};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (bin == j && left >= c[j]) {
+        left -= c[j];
+        bin = j + 1;
+      }
+    }
+    *npf = pf | ((unsigned long long)(4 * lane + bin) << shift);
+    *nrem = left;
+  }
+}
+
+__device__ __forceinline__ void write_result(const unsigned long long* prefix, const SelectArgs& sa, int s,
+                                             double* __restrict__ med_iqr) {
+  double v[NQ];
+  for (int q = 0; q < NQ; ++q) v[q] = __longlong_as_double((long long)prefix[q]);
+  const double med = sa.median_pair ? (v[0] + v[1]) / 2.0 : v[0];
+  double qv[2];
+  for (int h = 0; h < 2; ++h) {   // numpy _lerp
+    const double a = v[2 + 2 * h], b = v[3 + 2 * h], gm = sa.gamma[h];
+    const double diff = b - a;
+    double r = a + diff * gm;
+    if (gm >= 0.5) r = b - diff * (1.0 - gm);
+    qv[h] = r;
+  }
+  med_iqr[2 * s] = med;
+  med_iqr[2 * s + 1] = qv[1] - qv[0];
+}
+
+// FROM_B: read the compacted workspace buffer (flat) instead of the blocked input.
+// COMPACT: also write the matching keys to the workspace buffer.
+template <bool FROM_B, bool COMPACT>
+__global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, SelState* __restrict__ state,
+                                                          int pass) {
   __shared__ unsigned int hist[NQ][256];
   __shared__ unsigned long long stage[COMPACT ? SLICE : 1];
   __shared__ unsigned int n_stage, out_base, ticket_s;
+  __shared__ unsigned long long npf[NQ];
+  __shared__ int nrem[NQ];
   const int s = blockIdx.y, g = blockIdx.x, G = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   SelState& st = state[s];
-  const unsigned int cnt = st.cnt_in;
-  const unsigned long long* in = (st.src ? bufB : bufA) + (size_t)s * t;
-  unsigned long long* out = (st.src ? bufA : bufB) + (size_t)s * t;
+  const unsigned int slots = (unsigned int)kl.blocks * (unsigned int)kl.pitch;
+  const unsigned int cnt = FROM_B ? st.cnt_b : slots;
+  unsigned long long* outb = kl.bufb + (size_t)s * slots;
   const int shift = 56 - 8 * pass;
   unsigned long long pf[NQ];
   bool active[NQ];
@@ -104,26 +163,36 @@ __global__ __launch_bounds__(256) void select_pass_kernel(unsigned long long* __
   if (tid == 0) n_stage = 0u;
   __syncthreads();
 
-  // a block walks slices g, g+G, ... of the input (late passes are launched with few blocks per
-  // sensor because compaction normally leaves a handful of keys; any count stays correct)
+  // a block walks slices g, g+G, ... (any count stays correct when fewer blocks are launched)
   for (unsigned int base = (unsigned int)g * SLICE; base < cnt; base += (unsigned int)G * SLICE) {
+    // slice -> memory: blocked input (a slice never straddles two blocks: pitch % SLICE == 0 when
+    // blocks > 1) or the flat workspace buffer
+    const unsigned long long* in;
+    unsigned int lim;   // valid slots of this slice's row, from `base`
+    if (FROM_B) {
+      in = outb + base;
+      lim = cnt - base;
+    } else {
+      const unsigned int blk = base / (unsigned int)kl.pitch, off = base - blk * (unsigned int)kl.pitch;
+      in = kl.keys + ((size_t)blk * kl.n + s) * kl.pitch + off;
+      lim = (unsigned int)kl.pitch - off;
+    }
     unsigned long long key[8];
-    bool have[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const unsigned int i = base + tid + u * 256;
-      have[u] = i < cnt;
-      key[u] = in[min(i, cnt - 1)];
+      const unsigned int i = tid + u * 256;
+      key[u] = i < lim ? in[i] : FILLER;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      const bool real = key[u] != FILLER;
       const unsigned int digit = (unsigned int)(key[u] >> shift) & 255u;
       const unsigned int d0 = __builtin_amdgcn_readfirstlane(digit);
       bool any = false;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (!active[q]) continue;   // uniform
-        const bool match = have[u] && (pass == 0 ? true : ((key[u] ^ pf[q]) >> (shift + 8)) == 0ull);
+        const bool match = real && (pass == 0 ? true : ((key[u] ^ pf[q]) >> (shift + 8)) == 0ull);
         any |= match;
         if (__all(match && digit == d0)) {
           if (lane == 0) atomicAdd(&hist[q][d0], 64u);
@@ -136,27 +205,25 @@ __global__ __launch_bounds__(256) void select_pass_kernel(unsigned long long* __
       }
     }
     if constexpr (COMPACT) {
-      // flush this slice's survivors before the staging area is reused
       __syncthreads();
-      if (tid == 0) out_base = n_stage ? atomicAdd(&st.cnt_out, n_stage) : 0u;
+      if (tid == 0) out_base = n_stage ? atomicAdd(&st.cnt_b, n_stage) : 0u;
       __syncthreads();
-      for (unsigned int i = tid; i < n_stage; i += 256) out[out_base + i] = stage[i];
+      for (unsigned int i = tid; i < n_stage; i += 256) outb[out_base + i] = stage[i];
       __syncthreads();
       if (tid == 0) n_stage = 0u;
       __syncthreads();
     }
   }
   __syncthreads();
-  // contribute: non-empty bins -> the sensor's histogram; survivors -> the other buffer
   for (int i = tid; i < NQ * 256; i += 256) {
     const unsigned int c = (&hist[0][0])[i];
     if (c) atomicAdd(&(&st.hist[0][0])[i], c);
   }
-  // Hand-off without fences: every contribution the last block consumes (histogram bins, survivor
-  // count) is an agent-scope ATOMIC, performed at the device coherence point; each wave waits for
-  // its own atomics to be acknowledged, the barrier orders all waves before the ticket, and the last
-  // block reads the totals back with atomic exchanges (which also re-zero them).  The compacted keys
-  // are plain stores: they are only read by the NEXT launch.  (__threadfence() here costs a full L2
+  // Hand-off without fences: every value the last block consumes (histogram bins, survivor count)
+  // is an agent-scope ATOMIC performed at the device coherence point; each wave waits for its own
+  // atomics to be acknowledged, the barrier orders all waves before the ticket, and the last block
+  // reads the totals back with atomic exchanges (which also re-zero them).  The compacted keys are
+  // plain stores: only the NEXT launch reads them.  (A __threadfence() here costs a full L2
   // write-back per block: 150 us per pass with 2000 blocks.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -167,34 +234,7 @@ __global__ __launch_bounds__(256) void select_pass_kernel(unsigned long long* __
   // ---- last block of this sensor
   for (int i = tid; i < NQ * 256; i += 256) (&hist[0][0])[i] = atomicExch(&(&st.hist[0][0])[i], 0u);
   __syncthreads();
-  __shared__ unsigned long long npf[NQ];
-  __shared__ int nrem[NQ];
-  for (int q = wv; q < NQ; q += 4) {
-    const unsigned int* h = hist[st.rep[q]];
-    const uint4 c4 = *reinterpret_cast<const uint4*>(h + 4 * lane);
-    const int mine = (int)(c4.x + c4.y + c4.z + c4.w);
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(incl, d);
-      if (lane >= d) incl += up;
-    }
-    const int left0 = st.rem[q];
-    const int excl = incl - mine;
-    if (left0 >= excl && left0 < incl) {
-      int left = left0 - excl, bin = 0;
-      const int c[4] = {(int)c4.x, (int)c4.y, (int)c4.z, (int)c4.w};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (bin == j && left >= c[j]) {
-          left -= c[j];
-          bin = j + 1;
-        }
-      }
-      npf[q] = pf[q] | ((unsigned long long)(4 * lane + bin) << shift);
-      nrem[q] = left;
-    }
-  }
+  for (int q = wv; q < NQ; q += 4) locate_bin(hist[st.rep[q]], st.rem[q], pf[q], shift, lane, &npf[q], &nrem[q]);
   __syncthreads();
   if (tid < NQ) {
     st.prefix[tid] = npf[tid];
@@ -204,37 +244,17 @@ __global__ __launch_bounds__(256) void select_pass_kernel(unsigned long long* __
       if (npf[q] == npf[tid]) r = q;
     st.rep[tid] = r;
   }
-  if (tid == 0) {
-    atomicExch(&st.arrive, 0u);
-    if (COMPACT) {
-      st.cnt_in = atomicExch(&st.cnt_out, 0u);
-      st.src ^= 1u;
-    }
-    if (pass == 7) {
-      double v[NQ];
-      for (int q = 0; q < NQ; ++q) v[q] = __longlong_as_double((long long)npf[q]);
-      const double med = sa.median_pair ? (v[0] + v[1]) / 2.0 : v[0];
-      double qv[2];
-      for (int h = 0; h < 2; ++h) {   // numpy _lerp
-        const double a = v[2 + 2 * h], b = v[3 + 2 * h], gm = sa.gamma[h];
-        const double diff = b - a;
-        double r = a + diff * gm;
-        if (gm >= 0.5) r = b - diff * (1.0 - gm);
-        qv[h] = r;
-      }
-      med_iqr[2 * s] = med;
-      med_iqr[2 * s + 1] = qv[1] - qv[0];
-    }
-  }
+  if (tid == 0) atomicExch(&st.arrive, 0u);
 }
 
 // Finisher: digits first_pass..7 of every rank in ONE launch, one block per sensor, no global
-// hand-offs.  Runs after the compacting passes, when a sensor normally has a handful of keys left
-// (<= 2048 stay in registers; more — e.g. thousands of identical values — are re-read per digit).
-__global__ __launch_bounds__(256) void select_finish_kernel(const unsigned long long* __restrict__ bufA,
-                                                            const unsigned long long* __restrict__ bufB,
-                                                            SelState* __restrict__ state, int t, int first_pass,
-                                                            const SelectArgs sa, double* __restrict__ med_iqr) {
+// hand-offs.  Reads the compacted buffer (FROM_B) — normally a handful of keys, <= 2048 stay in
+// registers, more (e.g. thousands of identical values) are re-read per digit — or, for inputs of a
+// single slice, the flat input itself.
+template <bool FROM_B>
+__global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, SelState* __restrict__ state,
+                                                            int first_pass, const SelectArgs sa,
+                                                            double* __restrict__ med_iqr) {
   __shared__ unsigned int hist[NQ][256];
   __shared__ unsigned long long prefix[NQ];
   __shared__ int rem[NQ];
@@ -242,8 +262,9 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const unsigned long 
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   SelState& st = state[s];
-  const unsigned int cnt = st.cnt_in;
-  const unsigned long long* in = (st.src ? bufB : bufA) + (size_t)s * t;
+  const unsigned int slots = (unsigned int)kl.blocks * (unsigned int)kl.pitch;
+  const unsigned int cnt = FROM_B ? st.cnt_b : slots;
+  const unsigned long long* in = FROM_B ? kl.bufb + (size_t)s * slots : kl.keys + (size_t)s * kl.pitch;
   if (tid < NQ) {
     prefix[tid] = st.prefix[tid];
     rem[tid] = st.rem[tid];
@@ -252,7 +273,10 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const unsigned long 
   unsigned long long key[8];
   if (resident) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) key[u] = in[min((unsigned int)(tid + u * 256), cnt - 1)];
+    for (int u = 0; u < 8; ++u) {
+      const unsigned int i = tid + u * 256;
+      key[u] = i < cnt ? in[i] : FILLER;
+    }
   }
   __syncthreads();
   for (int pass = first_pass; pass < 8; ++pass) {
@@ -272,64 +296,25 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const unsigned long 
       pf[q] = prefix[q];
       active[q] = rep[q] == q;
     }
-    auto tally = [&](unsigned long long k, bool have) {
+    auto tally = [&](unsigned long long k) {
       const unsigned int digit = (unsigned int)(k >> shift) & 255u;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (!active[q]) continue;
-        if (have && (pass == 0 || ((k ^ pf[q]) >> (shift + 8)) == 0ull)) atomicAdd(&hist[q][digit], 1u);
+        if (k != FILLER && (pass == 0 || ((k ^ pf[q]) >> (shift + 8)) == 0ull)) atomicAdd(&hist[q][digit], 1u);
       }
     };
     if (resident) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) tally(key[u], (unsigned int)(tid + u * 256) < cnt);
+      for (int u = 0; u < 8; ++u) tally(key[u]);
     } else {
-      for (unsigned int i = tid; i < cnt; i += 256) tally(in[i], true);
+      for (unsigned int i = tid; i < cnt; i += 256) tally(in[i]);
     }
     __syncthreads();
-    for (int q = wv; q < NQ; q += 4) {
-      const unsigned int* h = hist[rep[q]];
-      const uint4 c4 = *reinterpret_cast<const uint4*>(h + 4 * lane);
-      const int mine = (int)(c4.x + c4.y + c4.z + c4.w);
-      int incl = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-      }
-      const int left0 = rem[q];
-      const int excl = incl - mine;
-      if (left0 >= excl && left0 < incl) {
-        int left = left0 - excl, bin = 0;
-        const int c[4] = {(int)c4.x, (int)c4.y, (int)c4.z, (int)c4.w};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (bin == j && left >= c[j]) {
-            left -= c[j];
-            bin = j + 1;
-          }
-        }
-        prefix[q] |= (unsigned long long)(4 * lane + bin) << shift;
-        rem[q] = left;
-      }
-    }
+    for (int q = wv; q < NQ; q += 4) locate_bin(hist[rep[q]], rem[q], pf[q], shift, lane, &prefix[q], &rem[q]);
     __syncthreads();
   }
-  if (tid == 0) {
-    double v[NQ];
-    for (int q = 0; q < NQ; ++q) v[q] = __longlong_as_double((long long)prefix[q]);
-    const double med = sa.median_pair ? (v[0] + v[1]) / 2.0 : v[0];
-    double qv[2];
-    for (int h = 0; h < 2; ++h) {   // numpy _lerp
-      const double a = v[2 + 2 * h], b = v[3 + 2 * h], gm = sa.gamma[h];
-      const double diff = b - a;
-      double r = a + diff * gm;
-      if (gm >= 0.5) r = b - diff * (1.0 - gm);
-      qv[h] = r;
-    }
-    med_iqr[2 * s] = med;
-    med_iqr[2 * s + 1] = qv[1] - qv[0];
-  }
+  if (tid == 0) write_result(prefix, sa, s, med_iqr);
 }
 
 // Normalise, smooth, max.  One wave owns a run of consecutive ticks; lane l owns sensors l, l+64, ...
@@ -397,54 +382,90 @@ __global__ __launch_bounds__(256) void score_smooth_max_kernel(
 
 }  // namespace
 
-// workspace: two key buffers [n,t] (u64 bit patterns of |pred-gt|) + one SelState per sensor
+namespace {
+
+SelectArgs make_select_args(long long t) {
+  SelectArgs sa;
+  // np.median: middle value, or the mean of the two middle values when t is even
+  sa.median_pair = (t % 2 == 0);
+  sa.rank[0] = (int)(sa.median_pair ? t / 2 - 1 : (t - 1) / 2);
+  sa.rank[1] = (int)(sa.median_pair ? t / 2 : (t - 1) / 2);
+  // np.percentile(method='linear'): virtual index n*q + (alpha + q*(1-alpha-beta)) - 1, alpha=beta=1
+  const double qs[2] = {25.0 / 100.0, 75.0 / 100.0};
+  for (int h = 0; h < 2; ++h) {
+    const double vi = (double)t * qs[h] + (1.0 + qs[h] * (1.0 - 1.0 - 1.0)) - 1.0;
+    const double lo = floor(vi);
+    long long ilo = (long long)lo, ihi = ilo + 1;
+    if (ilo < 0) ilo = 0;
+    if (ihi > t - 1) ihi = t - 1;
+    if (ilo > t - 1) ilo = t - 1;
+    sa.rank[2 + 2 * h] = (int)ilo;
+    sa.rank[3 + 2 * h] = (int)ihi;
+    sa.gamma[h] = vi - lo;
+  }
+  return sa;
+}
+
+int run_select(const double* keys, int blocks, int n, int pitch, long long total, double* workspace,
+               double* med_iqr, hipStream_t st) {
+  const long long slots = (long long)blocks * pitch;
+  KeyLayout kl;
+  kl.keys = reinterpret_cast<const unsigned long long*>(keys);
+  kl.bufb = reinterpret_cast<unsigned long long*>(workspace);
+  kl.blocks = blocks; kl.n = n; kl.pitch = pitch;
+  SelState* state = reinterpret_cast<SelState*>(kl.bufb + (size_t)slots * n);
+  const SelectArgs sa = make_select_args(total);
+  const int slices = (int)((slots + SLICE - 1) / SLICE);
+  hipLaunchKernelGGL(select_init_kernel, dim3(n), dim3(256), 0, st, state, sa);
+  if (slices == 1) {   // tiny input: everything in the finisher, straight from the input
+    hipLaunchKernelGGL(select_finish_kernel<false>, dim3(n), dim3(256), 0, st, kl, state, 0, sa, med_iqr);
+    return gdn_launch_status();
+  }
+  hipLaunchKernelGGL((select_pass_kernel<false, false>), dim3(slices, n), dim3(256), 0, st, kl, state, 0);
+  hipLaunchKernelGGL((select_pass_kernel<false, false>), dim3(slices, n), dim3(256), 0, st, kl, state, 1);
+  hipLaunchKernelGGL((select_pass_kernel<false, true>), dim3(slices, n), dim3(256), 0, st, kl, state, 2);
+  hipLaunchKernelGGL((select_pass_kernel<true, false>), dim3(min(slices, 2), n), dim3(256), 0, st, kl, state, 3);
+  hipLaunchKernelGGL(select_finish_kernel<true>, dim3(n), dim3(256), 0, st, kl, state, 4, sa, med_iqr);
+  return gdn_launch_status();
+}
+
+}  // namespace
+
+// select workspace: compacted-key buffer [n][blocks*pitch] + one SelState per sensor
+extern "C" long long gdn_score_select_workspace_bytes(int blocks, int n, int pitch) {
+  if (blocks <= 0 || n <= 0 || pitch <= 0) return 0;
+  return (long long)blocks * pitch * n * 8 + (long long)n * (long long)sizeof(SelState) + 256;
+}
+
+// quantiles workspace: the key buffer [n][t] + the select workspace
 extern "C" long long gdn_score_workspace_bytes(int t, int n) {
   if (t <= 0 || n <= 0) return 0;
-  return 2ll * t * n * 8 + (long long)n * (long long)sizeof(SelState) + 256;
+  return (long long)t * n * 8 + gdn_score_select_workspace_bytes(1, n, t);
+}
+
+extern "C" int gdn_score_keys(const float* pred, const float* gt, int t, int n, int pitch, double* keys,
+                              void* stream) {
+  if (!pred || !gt || !keys || t <= 0 || n <= 0 || pitch < t) return GDN_ERR_ARG;
+  hipLaunchKernelGGL(score_keys_kernel, dim3((pitch + 63) / 64, (n + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, pred, gt, t, n, pitch, keys);
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_score_select(const double* keys, int blocks, int n, int pitch, long long total,
+                                double* workspace, double* med_iqr, void* stream) {
+  if (!keys || !workspace || !med_iqr || blocks <= 0 || n <= 0 || pitch <= 0 || total <= 0) return GDN_ERR_ARG;
+  if (total > (long long)blocks * pitch || (long long)blocks * pitch > 0x7fffffffll) return GDN_ERR_ARG;
+  if (blocks > 1 && pitch % SLICE != 0) return GDN_ERR_UNSUPPORTED;   // slices must not straddle blocks
+  return run_select(keys, blocks, n, pitch, total, workspace, med_iqr, (hipStream_t)stream);
 }
 
 extern "C" int gdn_score_quantiles(const float* pred, const float* gt, int t, int n, double* workspace,
                                    double* med_iqr, void* stream) {
   if (!pred || !gt || !workspace || !med_iqr || t <= 0 || n <= 0) return GDN_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(score_delta_kernel, dim3((t + 63) / 64, (n + 63) / 64), dim3(256), 0, st, pred, gt, t,
-                     n, workspace);
-  SelectArgs sa;
-  // np.median: middle value, or the mean of the two middle values when t is even
-  sa.median_pair = (t % 2 == 0);
-  sa.rank[0] = sa.median_pair ? t / 2 - 1 : (t - 1) / 2;
-  sa.rank[1] = sa.median_pair ? t / 2 : (t - 1) / 2;
-  // np.percentile(method='linear'): virtual index n*q + (alpha + q*(1-alpha-beta)) - 1, alpha=beta=1
-  const double qs[2] = {25.0 / 100.0, 75.0 / 100.0};
-  for (int h = 0; h < 2; ++h) {
-    const double vi = (double)t * qs[h] + (1.0 + qs[h] * (1.0 - 1.0 - 1.0)) - 1.0;
-    double lo = floor(vi);
-    int ilo = (int)lo, ihi = ilo + 1;
-    if (ilo < 0) ilo = 0;
-    if (ihi > t - 1) ihi = t - 1;
-    if (ilo > t - 1) ilo = t - 1;
-    sa.rank[2 + 2 * h] = ilo;
-    sa.rank[3 + 2 * h] = ihi;
-    sa.gamma[h] = vi - lo;
-  }
-  unsigned long long* bufA = reinterpret_cast<unsigned long long*>(workspace);
-  unsigned long long* bufB = bufA + (size_t)t * n;
-  SelState* state = reinterpret_cast<SelState*>(bufB + (size_t)t * n);
-  const int slices = (t + SLICE - 1) / SLICE;
-  hipLaunchKernelGGL(select_init_kernel, dim3(n), dim3(256), 0, st, state, n, t, sa);
-  // digits 0-1 (exponent bytes: no point compacting), 2-3 compacting (3 normally sees a few
-  // thousand keys per sensor: two blocks each), then one finisher launch for digits 4-7
-  const int wide = slices > 1 ? 4 : 0;   // a single slice goes straight to the finisher
-  for (int pass = 0; pass < wide; ++pass) {
-    if (pass < 2)
-      hipLaunchKernelGGL(select_pass_kernel<false>, dim3(slices, n), dim3(256), 0, st, bufA, bufB, state, t,
-                         pass, sa, med_iqr);
-    else
-      hipLaunchKernelGGL(select_pass_kernel<true>, dim3(pass == 2 ? slices : min(slices, 2), n), dim3(256), 0,
-                         st, bufA, bufB, state, t, pass, sa, med_iqr);
-  }
-  hipLaunchKernelGGL(select_finish_kernel, dim3(n), dim3(256), 0, st, bufA, bufB, state, t, wide, sa, med_iqr);
-  return gdn_launch_status();
+  double* keys = workspace;
+  const int rc = gdn_score_keys(pred, gt, t, n, t, keys, stream);
+  if (rc != GDN_OK) return rc;
+  return run_select(keys, 1, n, t, t, workspace + (size_t)t * n, med_iqr, (hipStream_t)stream);
 }
 
 extern "C" int gdn_score_smooth_max(const float* pred, const float* gt, const double* med_iqr, int t, int n,

@@ -125,13 +125,20 @@ def broadcast_parameters(model, src: int = 0) -> None:
         dist.broadcast(t.data, src=src)
 
 
+KEY_SLICE = 2048    # the select kernel's slice: exchanged key rows are padded to a multiple of it
+
+
 class HipScoreBackend:
     """Per-rank compute of the distributed scoring; tests inject an oracle-backed stand-in to
     exercise the exchange logic on CPU (gloo)."""
 
     @staticmethod
-    def quantiles(pred_tn, gt_tn):
-        return ops.score_quantiles(pred_tn, gt_tn)
+    def keys(pred_tn, gt_tn, pitch):
+        return ops.score_keys(pred_tn, gt_tn, pitch)
+
+    @staticmethod
+    def select(keys_flat, blocks, n, pitch, total):
+        return ops.score_select(keys_flat, blocks, n, pitch, total)
 
     @staticmethod
     def smooth_max(pred_tn, gt_tn, med_iqr, first_tick, halo_pred, halo_gt):
@@ -139,65 +146,71 @@ class HipScoreBackend:
                                     halo_pred=halo_pred, halo_gt=halo_gt)[1]
 
 
-def distributed_anomaly(pred_local, gt_local, total_ticks: int, backend=HipScoreBackend, group=None):
+def distributed_anomaly(pred_local, gt_local, total_ticks: int, backend=HipScoreBackend, group=None,
+                        rehearse: bool = False):
     """Anomaly score of a series whose ticks are sharded contiguously over the ranks.
 
-    Step 1  all-to-all by sensor: rank r receives, from every rank, that rank's ticks of the
-            sensors r owns -> it holds all T ticks of its sensors and selects their median / IQR.
+    Step 1  every rank turns ITS ticks into radix keys |pred-gt| (float64), already transposed to
+            [sensor, tick] and padded to a common pitch, so the rows of the sensors rank r owns are one
+            contiguous chunk: `all_to_all_single` sends them with no packing, and rank r selects
+            median / IQR of its sensors straight over the received [rank, sensor, pitch] blocks
+            (padding is a filler the select ignores) — no unpacking either.
     Step 2  all-gather of the per-sensor [median, IQR] rows -> every rank has the [N,2] table.
     Step 3  each rank normalises / smooths / maxes its own ticks; the 3-tick halo before its first
-            tick comes from the previous rank (point-to-point via all_gather of the last 3 rows).
+            tick comes from its predecessors (all-gather of every rank's last <=3 rows).
     Returns anomaly[local ticks] (float64).  Single process: plain local scoring."""
     rank, size = world()
     t_local, n = pred_local.shape
-    if size == 1:
-        med_iqr = backend.quantiles(pred_local, gt_local)
+    if size == 1 and not (rehearse and dist.is_initialized()):
+        keys = backend.keys(pred_local, gt_local, t_local)
+        med_iqr = backend.select(keys, 1, n, t_local, t_local)
         return backend.smooth_max(pred_local, gt_local, med_iqr, 0, None, None)
+    # (rehearse: run the full exchange with a 1-rank process group — exercises the RCCL calls on a
+    # one-GPU box)
     dev = pred_local.device
     bounds = [shard_range(total_ticks, r, size) for r in range(size)]
     sens = [sensor_range(n, r, size) for r in range(size)]
     s0, s1 = sens[rank]
-    # ---- step 1: exchange (pred, gt) columns; payload to rank r = my ticks x r's sensors.
-    # all_to_all_single (split sizes) is the one all-to-all both RCCL and gloo implement.
-    send = torch.cat([torch.stack((pred_local[:, a:b], gt_local[:, a:b])).reshape(-1) for a, b in sens])
-    in_sizes = [2 * t_local * (b - a) for a, b in sens]
-    out_sizes = [2 * (e - s) * (s1 - s0) for s, e in bounds]
-    flat = torch.empty((sum(out_sizes),), dtype=pred_local.dtype, device=dev)
-    dist.all_to_all_single(flat, send, out_sizes, in_sizes, group=group)
-    recv, off = [], 0
-    for (s, e), size_r in zip(bounds, out_sizes):
-        recv.append(flat[off:off + size_r].view(2, e - s, s1 - s0))
-        off += size_r
-    mine = torch.cat(recv, dim=1)                                   # [2, T, my sensors]
-    if s1 > s0:
-        my_mi = backend.quantiles(mine[0].contiguous(), mine[1].contiguous()).to(torch.float64)
+    n_mine = s1 - s0
+    # ---- step 1
+    longest = max(e - s for s, e in bounds)
+    pitch = max(KEY_SLICE, (longest + KEY_SLICE - 1) // KEY_SLICE * KEY_SLICE)
+    if t_local > 0:
+        send = backend.keys(pred_local, gt_local, pitch)                 # [n, pitch], rows grouped by owner
+    else:
+        send = torch.full((n, pitch), -1, dtype=torch.int64, device=dev).view(torch.float64)   # all filler
+    in_sizes = [(b - a) * pitch for a, b in sens]
+    out_sizes = [n_mine * pitch] * size
+    recv = torch.empty((size * n_mine * pitch,), dtype=torch.float64, device=dev)
+    dist.all_to_all_single(recv, send.reshape(-1), out_sizes, in_sizes, group=group)
+    if n_mine:
+        my_mi = backend.select(recv, size, n_mine, pitch, total_ticks).to(torch.float64)
     else:
         my_mi = torch.empty((0, 2), dtype=torch.float64, device=dev)
-    # ---- step 2: all-gather the table (ragged -> pad to the largest sensor share)
+    # ---- steps 2+3 in ONE all-gather: every rank publishes [its median/IQR rows (padded to the
+    # largest sensor share) | its last <=3 (pred, gt) rows, right-aligned, as float64 (lossless)].
+    # The halo = the 3 ticks before my first one; a shard shorter than 3 ticks makes it span several
+    # predecessors.
     cap = max(b - a for a, b in sens)
-    padded = torch.zeros((cap, 2), dtype=torch.float64, device=dev)
-    padded[: s1 - s0] = my_mi
-    gathered = [torch.empty_like(padded) for _ in range(size)]
-    dist.all_gather(gathered, padded, group=group)
-    med_iqr = torch.cat([g[: b - a] for g, (a, b) in zip(gathered, sens)]).contiguous()
-    # ---- step 3: halo = the 3 ticks before my first one.  Every rank publishes its last <=3 rows
-    # (right-aligned); a shard shorter than 3 ticks makes the halo span several predecessors.
-    tail = torch.zeros((2, 3, n), dtype=pred_local.dtype, device=dev)
+    pub = torch.zeros((cap * 2 + 6 * n,), dtype=torch.float64, device=dev)
+    pub[: n_mine * 2] = my_mi.reshape(-1)
     take = min(3, t_local)
     if take:
+        tail = pub[cap * 2:].view(2, 3, n)
         tail[0, 3 - take:] = pred_local[t_local - take:]
         tail[1, 3 - take:] = gt_local[t_local - take:]
-    tails = [torch.empty_like(tail) for _ in range(size)]
-    dist.all_gather(tails, tail, group=group)
+    gathered = [torch.empty_like(pub) for _ in range(size)]
+    dist.all_gather(gathered, pub, group=group)
+    med_iqr = torch.cat([g[: (b - a) * 2].view(-1, 2) for g, (a, b) in zip(gathered, sens)]).contiguous()
     first_tick = bounds[rank][0]
     halo_p = halo_g = None
     if first_tick > 0:
-        rows = [torch.zeros((2, 3, n), dtype=pred_local.dtype, device=dev)]   # ticks "before 0": never read
+        rows = [torch.zeros((2, 3, n), dtype=torch.float64, device=dev)]      # ticks "before 0": never read
         for r in range(rank):
             have = min(3, bounds[r][1] - bounds[r][0])
             if have:
-                rows.append(tails[r][:, 3 - have:])
-        prev = torch.cat(rows, dim=1)[:, -3:]
+                rows.append(gathered[r][cap * 2:].view(2, 3, n)[:, 3 - have:])
+        prev = torch.cat(rows, dim=1)[:, -3:].to(pred_local.dtype)
         halo_p, halo_g = prev[0].contiguous(), prev[1].contiguous()
     if t_local == 0:
         return torch.empty((0,), dtype=torch.float64, device=dev)

@@ -198,6 +198,25 @@ def score_workspace(t: int, n: int, device) -> torch.Tensor:
     return torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=device)
 
 
+def score_keys(pred, gt, pitch: int) -> torch.Tensor:
+    """keys[n, pitch] float64 = |pred-gt| transposed (radix keys); slots t..pitch-1 = filler."""
+    pred, gt = _chk(pred, name="pred"), _chk(gt, name="gt")
+    t, n = pred.shape
+    keys = torch.empty((n, pitch), dtype=torch.float64, device=pred.device)
+    _lib.call("gdn_score_keys", _ptr(pred), _ptr(gt), t, n, pitch, _ptr(keys), _stream())
+    return keys
+
+
+def score_select(keys, blocks: int, n: int, pitch: int, total: int) -> torch.Tensor:
+    """Median / IQR per sensor over keys[blocks, n, pitch] holding `total` real keys per sensor."""
+    keys = _chk(keys, torch.float64, "keys")
+    nbytes = _lib.load().gdn_score_select_workspace_bytes(blocks, n, pitch)
+    ws = torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=keys.device)
+    out = torch.empty((n, 2), dtype=torch.float64, device=keys.device)
+    _lib.call("gdn_score_select", _ptr(keys), blocks, n, pitch, total, _ptr(ws), _ptr(out), _stream())
+    return out
+
+
 def score_quantiles(pred, gt):
     """Per-sensor median and IQR of |pred-gt| over all ticks (util/data.py:75-82), float64.
     pred, gt: fp32 [t, n].  Returns med_iqr[n, 2]."""

@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 4
+#define GDN_ABI_VERSION 5
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -165,6 +165,17 @@ int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, cons
  *     precede tick 0 are never read); scores[n,t] float64 (optional, NULL to skip) and
  *     anomaly[t] float64 = max over sensors.                                            */
 long long gdn_score_workspace_bytes(int t, int n);
+/* The two halves of gdn_score_quantiles, separable for the multi-GPU exchange (each rank builds the
+ * keys of its own ticks, rows are exchanged by sensor, the owner selects over every rank's block):
+ *   gdn_score_keys:   keys[n, pitch] float64 = |pred-gt| transposed; slots t..pitch-1 hold a filler
+ *                     (bit pattern of all ones) that the select ignores.  pitch >= t.
+ *   gdn_score_select: keys[blocks, n, pitch] (block r = the rows received from rank r), `total` real
+ *                     keys per sensor -> med_iqr[n,2].  The input is not modified.  blocks > 1
+ *                     needs pitch % 2048 == 0.  workspace: gdn_score_select_workspace_bytes bytes. */
+long long gdn_score_select_workspace_bytes(int blocks, int n, int pitch);
+int gdn_score_keys(const float* pred, const float* gt, int t, int n, int pitch, double* keys, void* stream);
+int gdn_score_select(const double* keys, int blocks, int n, int pitch, long long total,
+                     double* workspace, double* med_iqr, void* stream);
 int gdn_score_quantiles(const float* pred, const float* gt, int t, int n,
                         double* workspace, double* med_iqr, void* stream);
 int gdn_score_smooth_max(const float* pred, const float* gt, const double* med_iqr,

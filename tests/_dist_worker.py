@@ -17,10 +17,25 @@ from oracle import score_oracle  # noqa: E402
 
 
 class OracleScoreBackend:
+    """CPU stand-in for HipScoreBackend: same three entry points, arithmetic from the oracle / numpy."""
+
     @staticmethod
-    def quantiles(pred_tn, gt_tn):
-        rows = [score_oracle.err_median_and_iqr(pred_tn[:, i].numpy(), gt_tn[:, i].numpy())
-                for i in range(pred_tn.shape[1])]
+    def keys(pred_tn, gt_tn, pitch):
+        t, n = pred_tn.shape
+        k = torch.full((n, pitch), float("nan"), dtype=torch.float64)          # filler slots
+        k[:, :t] = (pred_tn.double() - gt_tn.double()).abs().t()
+        return k
+
+    @staticmethod
+    def select(keys_flat, blocks, n, pitch, total):
+        k = keys_flat.reshape(blocks, n, pitch).numpy()
+        rows = []
+        for s in range(n):
+            v = k[:, s, :].reshape(-1)
+            v = v[~np.isnan(v)]
+            assert v.size == total, (v.size, total)
+            from scipy.stats import iqr
+            rows.append((np.median(v), iqr(v)))                                # util/data.py:79-80
         return torch.tensor(rows, dtype=torch.float64).reshape(-1, 2)
 
     @staticmethod

@@ -154,3 +154,27 @@ def test_captured_graph_is_dropped_when_a_parameter_changes(gpu_device):
     ev.step()
     torch.cuda.synchronize()
     assert torch.allclose(ev.pred, before + 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("t,n,ranks", [(5000, 23, 3), (32768 * 2, 16, 2), (2500, 7, 4)])
+def test_blocked_key_select_equals_whole_series_quantiles(t, n, ranks, gpu_device):
+    """The owner-side half of the multi-GPU exchange on one GPU: keys built shard by shard (padded
+    pitch, filler slots), laid out [rank, sensor, pitch] as all_to_all_single delivers them, selected
+    in place — must equal the single-shot median / IQR bit for bit."""
+    from gdn_amd import harness, ops
+    g = torch.Generator().manual_seed(t)
+    pred = torch.rand((t, n), generator=g).to(gpu_device)
+    gt = (pred + 0.1 * torch.randn((t, n), generator=g).to(gpu_device)).contiguous()
+    want = ops.score_quantiles(pred, gt)
+    bounds = [harness.shard_range(t, r, ranks) for r in range(ranks)]
+    longest = max(e - s for s, e in bounds)
+    pitch = (longest + harness.KEY_SLICE - 1) // harness.KEY_SLICE * harness.KEY_SLICE
+    blocks = [ops.score_keys(pred[s:e].contiguous(), gt[s:e].contiguous(), pitch) for s, e in bounds]
+    for a, b in [harness.sensor_range(n, r, ranks) for r in range(ranks)]:
+        if b == a:
+            continue
+        recv = torch.stack([blk[a:b] for blk in blocks]).contiguous()        # [ranks, sensors, pitch]
+        keep = recv.clone()
+        got = ops.score_select(recv.reshape(-1), ranks, b - a, pitch, t)
+        assert torch.equal(got, want[a:b])
+        assert torch.equal(recv.view(torch.int64), keep.view(torch.int64))   # the input is not modified
