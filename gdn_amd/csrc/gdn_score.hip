@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void score_keys_kernel(const float* __restrict
 // non-empty bins to the sensor's global histogram and takes a ticket; the LAST block of a sensor
 // (no spinning, no fences: every consumed value is an agent-scope atomic) locates every rank's bin
 // and extends the prefixes for the next launch.  The digit-2 launch also compacts the matching keys
-// (normally a few percent) into the workspace; digit 3 runs on those, and one single-block finisher
-// launch per sensor does digits 4-7.
+// (normally a few percent) into the workspace, and one single-block finisher launch per sensor does
+// digits 3-7 on those.
 constexpr int SLICE = 2048;
 
 struct SelState {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, Se
 
 // Finisher: digits first_pass..7 of every rank in ONE launch, one block per sensor, no global
 // hand-offs.  Reads the compacted buffer (FROM_B) — normally a handful of keys, <= 2048 stay in
-// registers, more (e.g. thousands of identical values) are re-read per digit — or, for inputs of a
+// registers (<= 4096), more (e.g. thousands of identical values) are re-read per digit — or, for inputs of a
 // single slice, the flat input itself.
 template <bool FROM_B>
 __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, SelState* __restrict__ state,
@@ -269,11 +269,12 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, 
     prefix[tid] = st.prefix[tid];
     rem[tid] = st.rem[tid];
   }
-  const bool resident = cnt <= SLICE;
-  unsigned long long key[8];
+  constexpr int FK = 16;                      // keys per thread the finisher keeps in registers
+  const bool resident = cnt <= FK * 256;
+  unsigned long long key[FK];
   if (resident) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < FK; ++u) {
       const unsigned int i = tid + u * 256;
       key[u] = i < cnt ? in[i] : FILLER;
     }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, 
     };
     if (resident) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) tally(key[u]);
+      for (int u = 0; u < FK; ++u) tally(key[u]);
     } else {
       for (unsigned int i = tid; i < cnt; i += 256) tally(in[i]);
     }
@@ -424,8 +425,8 @@ int run_select(const double* keys, int blocks, int n, int pitch, long long total
   hipLaunchKernelGGL((select_pass_kernel<false, false>), dim3(slices, n), dim3(256), 0, st, kl, state, 0);
   hipLaunchKernelGGL((select_pass_kernel<false, false>), dim3(slices, n), dim3(256), 0, st, kl, state, 1);
   hipLaunchKernelGGL((select_pass_kernel<false, true>), dim3(slices, n), dim3(256), 0, st, kl, state, 2);
-  hipLaunchKernelGGL((select_pass_kernel<true, false>), dim3(min(slices, 2), n), dim3(256), 0, st, kl, state, 3);
-  hipLaunchKernelGGL(select_finish_kernel<true>, dim3(n), dim3(256), 0, st, kl, state, 4, sa, med_iqr);
+  // digits 3-7 on the survivors (normally a few percent of the keys) in one launch per sensor
+  hipLaunchKernelGGL(select_finish_kernel<true>, dim3(n), dim3(256), 0, st, kl, state, 3, sa, med_iqr);
   return gdn_launch_status();
 }
 
