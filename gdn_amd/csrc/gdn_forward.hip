@@ -303,7 +303,15 @@ __device__ __forceinline__ float ror_f(float v) {
 template <int D, int S0, int N = 8, int S = 0>
 __device__ __forceinline__ void fetch_half(const char* xl_lane, int jb, Pack<Geo<D>::VEC> (&buf)[N]) {
   if constexpr (S < N) {
+#if defined(GDN_ABLATE) && GDN_ABLATE == 2   // diagnostic build: no LDS row fetches (results are wrong)
+    {
+      const int o = ror_i<S0 + S>(jb);
+#pragma unroll
+      for (int v = 0; v < Geo<D>::VEC; ++v) buf[S].v[v] = __int_as_float(o + v);
+    }
+#else
     buf[S] = ld_pack<Geo<D>::VEC>(reinterpret_cast<const float*>(xl_lane + ror_i<S0 + S>(jb)));
+#endif
     fetch_half<D, S0, N, S + 1>(xl_lane, jb, buf);
   }
 }
@@ -311,7 +319,12 @@ __device__ __forceinline__ void fetch_half(const char* xl_lane, int jb, Pack<Geo
 template <int D, int S0, int N = 8, int S = 0>
 __device__ __forceinline__ void fma_half(float al, const Pack<Geo<D>::VEC> (&buf)[N], Pack<Geo<D>::VEC>& acc) {
   if constexpr (S < N) {
+#if defined(GDN_ABLATE) && GDN_ABLATE == 1   // diagnostic build: fetches kept alive, no FMAs / alpha moves
+#pragma unroll
+    for (int v = 0; v < Geo<D>::VEC; ++v) asm volatile("" ::"v"(buf[S].v[v]));
+#else
     axpy_pack<Geo<D>::VEC>(ror_f<S0 + S>(al), buf[S], acc);
+#endif
     fma_half<D, S0, N, S + 1>(al, buf, acc);
   }
 }
