@@ -330,3 +330,98 @@ class SeriesEvaluator:
             self.graph = self._capture(self._launch_all)
         self.graph.replay()
         return self.anomaly
+
+
+# --------------------------------------------------------------------------- graphed train step
+class GraphedTrainStep:
+    """One optimisation step of the reference's train() (train.py:52-66: zero_grad, forward, MSE,
+    backward, Adam) captured once in a HIP graph and replayed per minibatch.
+
+    At the reference's batch sizes a step is ~60 launches of a few microseconds each, so issuing
+    them from Python costs more than running them; a replayed graph removes that.  The graph
+    covers the per-step rebuild of the sensor graph and the folded attention terms (they depend
+    on the parameters Adam has just changed), the HIP forward/backward of the graph layer, torch's
+    BatchNorm/Linear/dropout kernels and a capturable Adam.  With more than one rank the step is
+    two graphs around the gradient all-reduce (`sync_gradients`), which stays eager.
+
+    `x` / `y` are the static input buffers: copy each minibatch into them, call `step()`, read
+    `loss` (a device scalar) whenever convenient."""
+
+    def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True):
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs the model on a HIP device")
+        dev = p0.device
+        n, w = model.embedding.weight.shape[0], model.gnn_layers[0].gnn.lin.weight.shape[1]
+        self.model = model.train()
+        self.x = torch.zeros((batch, n, w), dtype=torch.float32, device=dev)
+        self.y = torch.zeros((batch, n), dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
+        self.use_graph = use_graph
+        self._graphs = None
+        self._split = world()[1] > 1
+
+    # the two halves of a step; `loss` is written in place so it survives replays
+    def _forward_backward(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        out = self.model(self.x, None)
+        loss = F.mse_loss(out, self.y, reduction="mean")
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _update(self):
+        self.optimizer.step()
+
+    def _snapshot(self):
+        tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return tensors, [t.detach().clone() for t in tensors]
+
+    def _capture(self):
+        """Warm up on a side stream, capture, then put parameters, BN statistics and the Adam
+        state back to what they were: capturing must not train the model."""
+        tensors, saved = self._snapshot()
+        side = torch.cuda.Stream(device=self.x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._forward_backward()
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        if self._split:
+            for fn in (self._forward_backward, self._update):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                graphs.append(g)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._forward_backward()
+                self._update()
+            graphs.append(g)
+        with torch.no_grad():
+            for t, s in zip(tensors, saved):
+                t.copy_(s)
+            for state in self.optimizer.state.values():
+                for v in state.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        self._graphs = graphs
+
+    def step(self):
+        if not self.use_graph:
+            self._forward_backward()
+            sync_gradients(self.model)
+            self._update()
+            return self.loss
+        if self._graphs is None:
+            self._capture()
+        self._graphs[0].replay()
+        if self._split:
+            sync_gradients(self.model)
+            self._graphs[1].replay()
+        return self.loss

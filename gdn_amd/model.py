@@ -100,6 +100,28 @@ class _GraphAttentionFn(torch.autograd.Function):
         return None, d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb, d_bias, None, None
 
 
+class _HeadTrainFn(torch.autograd.Function):
+    """Train-mode BN+ReLU, x embedding, BN+ReLU, dropout, Linear(d->1) (models/GDN.py:77-79,:175-184)
+    as three streaming HIP passes forward and three backward; batch statistics in fp64."""
+
+    @staticmethod
+    def forward(ctx, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, lin_b, mask, bn1, bn2, batch):
+        out, stats = ops.head_train_fwd(z, emb, bn1, bn2, lin_w, lin_b, mask, batch)
+        ctx.save_for_backward(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, stats)
+        ctx.mask, ctx.eps, ctx.batch = mask, (float(bn1.eps), float(bn2.eps)), batch
+        ctx.shapes = (lin_w.shape, lin_b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, stats = ctx.saved_tensors
+        d_z, d_emb, g1w, g1b, g2w, g2b, glw, glb = ops.head_train_bwd(
+            d_out.contiguous(), z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, ctx.mask, stats,
+            ctx.eps[0], ctx.eps[1], ctx.batch)
+        return (d_z, d_emb, g1w, g1b, g2w, g2b, glw.view(ctx.shapes[0]), glb.view(ctx.shapes[1]),
+                None, None, None, None)
+
+
 class GNNLayer(nn.Module):
     """models/GDN.py:60-79.  `att_weight_1` / `edge_index_1` are materialised lazily in the
     reference's edge-list format from the dense per-target attention table."""
@@ -306,12 +328,32 @@ class GDN(nn.Module):
         z, alpha = _GraphAttentionFn.apply(x, gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i,
                                            gnn.att_em_j, emb, gnn.bias, c.graph, batch)
         layer._set_dense((alpha, c.graph, batch))
+        if self.out_layer_num == 1 and self._hip_train_head_ok():
+            lin = self.out_layer.mlp[0]
+            mask = self._dropout_mask(batch, node_num, emb.shape[1], x.device)
+            return _HeadTrainFn.apply(z, emb, layer.bn.weight, layer.bn.bias, self.bn_outlayer_in.weight,
+                                      self.bn_outlayer_in.bias, lin.weight, lin.bias, mask, layer.bn,
+                                      self.bn_outlayer_in, batch)
+        # out_layer_num > 1 (MLP head): torch for BN statistics, dropout and the library GEMMs
         h = layer.relu(layer.bn(z))                                         # GDN.py:77-79
         h = h.view(batch, node_num, -1)                                     # GDN.py:171-172
         h = torch.mul(h, emb)                                               # GDN.py:175-176
         h = F.relu(self.bn_outlayer_in(h.permute(0, 2, 1))).permute(0, 2, 1)   # GDN.py:178-180
         h = self.dp(h)                                                      # GDN.py:182
         return self.out_layer(h).view(-1, node_num)                         # GDN.py:183-184
+
+    def _hip_train_head_ok(self):
+        bns = (self.gnn_layers[0].bn, self.bn_outlayer_in)
+        return all(b.affine and (not b.track_running_stats or b.momentum is not None) for b in bns)
+
+    def _dropout_mask(self, batch, node_num, d, device):
+        """[B,N,d] multiplier of models/GDN.py:182 (0 or 1/(1-p)), drawn by `self.dp` itself so torch's
+        generator (and a replaced `dp` module) keep their meaning; None when dropout is off."""
+        dp = self.dp
+        if not dp.training or (isinstance(dp, nn.Dropout) and dp.p == 0):
+            return None
+        ones = torch.ones((batch, node_num, d), dtype=torch.float32, device=device)
+        return dp(ones).reshape(batch * node_num, d)
 
     def forward_into(self, data, out):
         """Eval fast path writing into a caller-owned [B, N] slice (no allocation, HIP-graph

@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 5
+#define GDN_ABI_VERSION 6
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -103,6 +103,35 @@ int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const float* s_j
 int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
                  const float* bn2_affine, const float* out_w, const float* out_b,
                  int batch, int n, int d, float* out, float* h2, void* stream);
+
+/* ---- train-mode head (out_layer_num == 1) -------------------------------------------
+ * gdn_head_train_fwd: the same chain as gdn_head_fwd under model.train(): both BatchNorms
+ * normalise by the statistics of this batch (models/GDN.py:77-79 GNNLayer.bn, :178-180
+ * bn_outlayer_in — biased variance over all batch*n rows) and update running_mean /
+ * running_var (momentum, unbiased variance) / num_batches_tracked; dropout (:182) is applied
+ * as the caller's mask[BN,d] (0 or 1/(1-p); NULL = no dropout); OutLayer Linear(d->1).
+ *   stats[4*d] double (out)  column sums of z, z^2, h1, h1^2 — kept for the backward.
+ *   running_* / batches*     may be NULL (track_running_stats off).
+ * Three streaming passes over z; nothing [BN,d]-sized is stored.  batch*n >= 2.             */
+int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                       const float* bn2_w, const float* bn2_b, const float* lin_w,
+                       const float* lin_b, const float* mask, int batch, int n, int d,
+                       float eps1, float eps2, float momentum1, float momentum2,
+                       float* running_mean1, float* running_var1, long long* batches1,
+                       float* running_mean2, float* running_var2, long long* batches2,
+                       double* stats, float* out, void* stream);
+
+/* gdn_head_train_bwd: gradients of gdn_head_train_fwd given d_out[BN] (what autograd derives
+ * for models/GDN.py:77-79,:175-184 in training): d_z[BN,d], d_emb[n,d] (the head's share of the
+ * embedding gradient), BatchNorm weight/bias gradients [d], OutLayer Linear d_lin_w[d] /
+ * d_lin_b[1].  workspace: gdn_head_train_workspace_bytes(n, d) bytes of scratch.            */
+long long gdn_head_train_workspace_bytes(int n, int d);
+int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, const float* bn1_w,
+                       const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                       const float* lin_w, const float* mask, const double* stats,
+                       int batch, int n, int d, float eps1, float eps2, double* workspace,
+                       float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
+                       float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);
 
 /* ---- fused eval forward (the throughput path) ---------------------------------------
  * Everything from x[batch,n,w] to out[batch,n] in one launch (one workgroup per window,
