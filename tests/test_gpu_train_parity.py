@@ -81,3 +81,103 @@ def test_two_adam_steps_match_reference_train_loop(gpu_device):
             # each step the two runs may move in opposite directions: up to ~2*lr apart per step
             atol = 4.5e-3
         np.testing.assert_allclose(val.cpu().numpy(), data["p_final/" + key], atol=atol, rtol=0, err_msg=key)
+
+
+def _torch_head(z, emb, bn1, bn2, lin_w, lin_b, mask, batch):
+    """fp64 torch restatement of models/GDN.py:77-79,:175-184 in training mode (the oracle's train branch
+    uses the same modules; this one exists so the kernel can be checked at shapes without a fixture)."""
+    n, d = emb.shape
+    h = torch.relu(torch.nn.functional.batch_norm(z, None, None, bn1[0], bn1[1], True, 0.0, 1e-5))
+    h = h.view(batch, n, d) * emb
+    h = torch.relu(torch.nn.functional.batch_norm(h.permute(0, 2, 1), None, None, bn2[0], bn2[1], True, 0.0,
+                                                  1e-5)).permute(0, 2, 1)
+    if mask is not None:
+        h = h * mask.view(batch, n, d)
+    return (h @ lin_w.view(d, 1)).view(batch, n) + lin_b
+
+
+@pytest.mark.parametrize("batch,n,d,use_mask", [(3, 7, 16, True), (5, 20, 32, False), (4, 127, 64, True),
+                                                (2, 40, 128, True), (1, 2, 64, False), (9, 700, 64, True)])
+def test_head_train_kernels_match_fp64_autograd(batch, n, d, use_mask, gpu_device):
+    """gdn_head_train_fwd / _bwd against torch autograd in float64 (incl. n*d beyond the LDS-resident
+    embedding-gradient partial: n=700, d=64)."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(batch * 1000 + n + d)
+    z = torch.randn((batch * n, d), generator=g) * 0.7 + 0.3
+    emb = torch.randn((n, d), generator=g)
+    prm = [torch.rand((d,), generator=g) + 0.5, torch.randn((d,), generator=g) * 0.2,
+           torch.rand((d,), generator=g) + 0.5, torch.randn((d,), generator=g) * 0.2,
+           torch.randn((1, d), generator=g) * 0.3, torch.randn((1,), generator=g)]
+    mask = ((torch.rand((batch * n, d), generator=g) > 0.2).float() / 0.8) if use_mask else None
+    d_out = torch.randn((batch, n), generator=g)
+
+    ref_in = [t.double().requires_grad_(True) for t in (z, emb, *prm)]
+    ref = _torch_head(ref_in[0], ref_in[1], ref_in[2:4], ref_in[4:6], ref_in[6], ref_in[7],
+                      None if mask is None else mask.double(), batch)
+    ref.backward(d_out.double())
+
+    bn1, bn2 = torch.nn.BatchNorm1d(d), torch.nn.BatchNorm1d(d)
+    with torch.no_grad():
+        bn1.weight.copy_(prm[0]); bn1.bias.copy_(prm[1]); bn2.weight.copy_(prm[2]); bn2.bias.copy_(prm[3])
+    bn1, bn2 = bn1.to(gpu_device), bn2.to(gpu_device)
+    zg, eg = z.to(gpu_device), emb.to(gpu_device)
+    mg = None if mask is None else mask.to(gpu_device)
+    lw, lb = prm[4].to(gpu_device), prm[5].to(gpu_device)
+    out, stats = ops.head_train_fwd(zg, eg, bn1, bn2, lw, lb, mg, batch)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    grads = ops.head_train_bwd(d_out.to(gpu_device), zg, eg, bn1.weight.detach(), bn1.bias.detach(),
+                               bn2.weight.detach(), bn2.bias.detach(), lw, mg, stats, 1e-5, 1e-5, batch)
+    names = ["d_z", "d_emb", "d_bn1_w", "d_bn1_b", "d_bn2_w", "d_bn2_b", "d_lin_w", "d_lin_b"]
+    for name, got, want in zip(names, grads, [t.grad for t in ref_in]):
+        want = want.reshape(got.shape).numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=3e-5 * scale, rtol=1e-4, err_msg=name)
+    # running statistics: momentum 0.1 from (0, 1), unbiased variance; batch counter
+    np.testing.assert_allclose(bn1.running_mean.cpu().numpy(), 0.1 * z.double().mean(0).numpy(), atol=1e-6)
+    np.testing.assert_allclose(bn1.running_var.cpu().numpy(),
+                               0.9 + 0.1 * z.double().var(0, unbiased=True).numpy(), atol=1e-5, rtol=1e-5)
+    assert int(bn1.num_batches_tracked) == 1 and int(bn2.num_batches_tracked) == 1
+
+
+def test_head_train_rejects_single_row(gpu_device):
+    """torch raises for train-mode BatchNorm over one value per channel; so does the kernel entry point."""
+    from gdn_amd import ops, _lib
+    bn1, bn2 = torch.nn.BatchNorm1d(64).to(gpu_device), torch.nn.BatchNorm1d(64).to(gpu_device)
+    z = torch.zeros((1, 64), device=gpu_device)
+    with pytest.raises(_lib.GdnHipError):
+        ops.head_train_fwd(z, torch.zeros((1, 64), device=gpu_device), bn1, bn2,
+                           torch.zeros((1, 64), device=gpu_device), torch.zeros((1,), device=gpu_device), None, 1)
+
+
+def test_graphed_train_step_equals_eager_steps(gpu_device):
+    """harness.GraphedTrainStep: replaying the captured step trains exactly like launching it eagerly
+    (dropout off so both draw no random numbers), and capturing does not move the parameters."""
+    from gdn_amd.harness import GraphedTrainStep
+    from test_gpu_forward_parity import random_params
+    b = 64
+    g = torch.Generator().manual_seed(5)
+    xs = torch.rand((4, b, 27, 10), generator=g).to(gpu_device)
+    ys = torch.rand((4, b, 27), generator=g).to(gpu_device)
+    finals = []
+    for use_graph in (False, True):
+        model = random_params(27, 10, 8, 64, seed=3).to(gpu_device)
+        model.dp.p = 0.0
+        before = [p.detach().clone() for p in model.parameters()]
+        step = GraphedTrainStep(model, b, use_graph=use_graph)
+        if use_graph:
+            step._capture()
+            for p, q in zip(model.parameters(), before):
+                assert torch.equal(p, q)
+        losses = []
+        for i in range(4):
+            step.x.copy_(xs[i]); step.y.copy_(ys[i])
+            losses.append(float(step.step()))
+        finals.append((losses, [p.detach().clone() for p in model.parameters()],
+                       [bf.detach().clone() for bf in model.buffers()]))
+    np.testing.assert_allclose(finals[0][0], finals[1][0], atol=1e-6)
+    names = [n for n, _ in model.named_parameters()]
+    for name, pa, pb in zip(names, finals[0][1], finals[1][1]):
+        # gnn.bias has zero true gradient under train-mode BN: Adam turns rounding noise into +-lr steps
+        tol = 4.5e-3 if name.endswith("gnn.bias") else 2e-5
+        np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), atol=tol, err_msg=name)
+    assert min(finals[1][0]) < finals[1][0][0]          # it trains
