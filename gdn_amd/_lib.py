@@ -27,6 +27,7 @@ SIGNATURES = {
     "gdn_head_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_head_train_fwd": [_p] * 9 + [_c_int] * 3 + [_c_float] * 4 + [_p] * 9,
     "gdn_head_train_workspace_bytes": [_c_int, _c_int],
+    "gdn_head_train_stats_bytes": [_c_int],
     "gdn_head_train_bwd": [_p] * 10 + [_c_int] * 3 + [_c_float] * 2 + [_p] * 10,
     "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],
     "gdn_forward_fused_series": [_p, _c_int, _c_int] + [_p] * 10 + [_c_int] * 5 + [_p, _p],
@@ -34,6 +35,7 @@ SIGNATURES = {
     "gdn_rev_pitch": [_c_int],
     "gdn_graph_reverse": [_p, _p, _c_int, _c_int, _p, _p, _p],
     "gdn_project_bwd": [_p] * 4 + [_c_int] * 4 + [_p] * 4,
+    "gdn_terms_bwd": [_p] * 8 + [_c_int] * 3 + [_p] * 7,
     "gdn_score_workspace_bytes": [_c_int, _c_int],
     "gdn_score_select_workspace_bytes": [_c_int, _c_int, _c_int],
     "gdn_score_keys": [_p, _p, _c_int, _c_int, _c_int, _p, _p],
@@ -66,7 +68,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_longlong if name.endswith("workspace_bytes") else _c_int
+        fn.restype = ctypes.c_longlong if name.endswith("_bytes") else _c_int
     if lib.gdn_abi_version() != ABI_VERSION:
         raise GdnHipError(f"ABI mismatch: library {lib.gdn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -340,6 +340,53 @@ __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
   for (int t = tid; t < 2 * n; t += nth) atomicAdd(&d_c[t], dc[t]);
 }
 
+// Chain rule through the folded constants a = lin^T att (node_terms) and c = emb . att_em:
+// d_lin_w += att_i (x) d_a[0] + att_j (x) d_a[1];  d_att = lin_w d_a;  d_att_em = emb^T d_c;
+// d_emb = d_c[0] (x) att_em_i + d_c[1] (x) att_em_j.  Tiny ([d,w], [n,d]); one launch instead of a dozen.
+__global__ __launch_bounds__(256) void gdn_terms_bwd_kernel(
+    const float* __restrict__ lin_w, const float* __restrict__ att_i, const float* __restrict__ att_j,
+    const float* __restrict__ att_em_i, const float* __restrict__ att_em_j, const float* __restrict__ emb,
+    const float* __restrict__ d_a, const float* __restrict__ d_c, int n, int d, int w,
+    float* __restrict__ d_lin_w, float* __restrict__ d_att_i, float* __restrict__ d_att_j,
+    float* __restrict__ d_att_em_i, float* __restrict__ d_att_em_j, float* __restrict__ d_emb) {
+  const int tid = threadIdx.x;
+  for (int t = blockIdx.x * 256 + tid; t < n * d; t += gridDim.x * 256) {
+    const int s = t / d, c = t - s * d;
+    d_emb[t] = fmaf(d_c[s], att_em_i[c], d_c[n + s] * att_em_j[c]);
+  }
+  if (blockIdx.x != 0) return;
+  __shared__ float part[4][256];
+  for (int t = tid; t < d * w; t += 256) {
+    const int c = t / w, q = t - c * w;
+    d_lin_w[t] += fmaf(att_i[c], d_a[q], att_j[c] * d_a[GDN_A_PITCH + q]);
+  }
+  // column c is handled by the 256/d threads tid = c, c+d, ...: strided partial sums, then an LDS reduce
+  const int c = tid % d, g = tid / d, groups = 256 / d;
+  float si = 0.f, sj = 0.f, ei = 0.f, ej = 0.f;
+  for (int q = g; q < w; q += groups) {
+    const float lw = lin_w[c * w + q];
+    si = fmaf(lw, d_a[q], si);
+    sj = fmaf(lw, d_a[GDN_A_PITCH + q], sj);
+  }
+  for (int s = g; s < n; s += groups) {
+    const float ev = emb[(size_t)s * d + c];
+    ei = fmaf(ev, d_c[s], ei);
+    ej = fmaf(ev, d_c[n + s], ej);
+  }
+  part[0][tid] = si; part[1][tid] = sj; part[2][tid] = ei; part[3][tid] = ej;
+  __syncthreads();
+  if (tid < d) {
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < groups; ++q)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) r[v] += part[v][q * d + tid];
+    d_att_i[tid] = r[0];
+    d_att_j[tid] = r[1];
+    d_att_em_i[tid] = r[2];
+    d_att_em_j[tid] = r[3];
+  }
+}
+
 template <typename K>
 int occupancy_grid(K kern, int threads, int lds, int batch) {
   int nb = 0;
@@ -432,5 +479,22 @@ extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float*
   }
 #undef GDN_PBD
 #undef GDN_PB
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_terms_bwd(const float* lin_w, const float* att_i, const float* att_j,
+                             const float* att_em_i, const float* att_em_j, const float* emb,
+                             const float* d_a, const float* d_c, int n, int d, int w, float* d_lin_w,
+                             float* d_att_i, float* d_att_j, float* d_att_em_i, float* d_att_em_j,
+                             float* d_emb, void* stream) {
+  if (!lin_w || !att_i || !att_j || !att_em_i || !att_em_j || !emb || !d_a || !d_c || !d_lin_w || !d_att_i ||
+      !d_att_j || !d_att_em_i || !d_att_em_j || !d_emb || n <= 0 || d <= 0 || w <= 0)
+    return GDN_ERR_ARG;
+  if (w > GDN_MAX_W || d > 256 || (256 % d) != 0) return GDN_ERR_UNSUPPORTED;
+  int grid = (n * d + 256 * 8 - 1) / (256 * 8);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(gdn_terms_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, lin_w, att_i, att_j,
+                     att_em_i, att_em_j, emb, d_a, d_c, n, d, w, d_lin_w, d_att_i, d_att_j, d_att_em_i,
+                     d_att_em_j, d_emb);
   return gdn_launch_status();
 }

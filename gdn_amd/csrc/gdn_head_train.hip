@@ -16,8 +16,9 @@
 // the accumulation order to fp32 precision.
 //
 // Thread layout: a row (one sensor of one window) is covered by LPR = d/4 consecutive lanes holding
-// four columns each; a workgroup owns whole windows, and lane group `slot` always works on sensors
-// slot, slot+SLOTS, ..., so per-(sensor, column) accumulators are private to a thread.
+// four columns each.  A workgroup takes SLOTS = 256/LPR consecutive sensors and a part of the batch;
+// lane group `slot` owns one sensor and walks the windows, four in flight, so the sensor's embedding
+// row and its embedding-gradient accumulator stay in registers and need no LDS or atomics per row.
 #include "gdn_common.hpp"
 
 namespace {
@@ -28,19 +29,31 @@ struct HG {
   static constexpr int SLOTS = 256 / LPR;
 };
 
+#define GDN_HEAD_REPL 4       // replicas of every column accumulator: same-address fp64 atomics serialise
+#define GDN_HEAD_EMB_PARTS 64  // batch parts of the embedding-gradient pass, one [n,d] partial each
+
 struct HeadArgs {
   const float *z, *emb, *g1, *b1, *g2, *b2, *w, *bo, *mask, *d_out;
-  const double* fstats;  // [4][d]: sum z, sum z^2, sum h1, sum h1^2
-  double* acc;           // forward passes: fstats (writable); backward: [6][d] + [n*d] workspace
+  const double* fstats;  // [REPL][4][d]: sum z, sum z^2, sum h1, sum h1^2
+  double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
+  float* demb_part;      // backward: [EMB_PARTS][n][d] per-part sums of d_emb
   float *out, *d_z;
   int batch, n;
   float eps1, eps2;
-  int demb_lds;          // the [n,d] embedding-gradient partial fits LDS
+  int chunks, parts;     // grid = chunks (of SLOTS sensors) x parts (of the batch)
 };
 
 struct BnCols {
   float mu[4], is[4], sc[4], be[4];
 };
+
+// sum of one accumulator row over its replicas; `stride` = doubles between replicas
+__device__ __forceinline__ double repl_sum(const double* p, int stride) {
+  double s = 0.0;
+#pragma unroll 4
+  for (int r = 0; r < GDN_HEAD_REPL; ++r) s += p[(size_t)r * stride];
+  return s;
+}
 
 __device__ __forceinline__ BnCols bn_cols(const double* sum, const double* sq, double rows, float eps,
                                           const float* gamma, const float* beta, int c0) {
@@ -82,163 +95,189 @@ __device__ __forceinline__ void col_reduce(const double (&v)[4], double* red, do
 
 enum { H_STAT1 = 0, H_STAT2 = 1, H_OUT = 2, H_BWD2 = 3, H_BWD1 = 4, H_DZ = 5 };
 
+#define GDN_HEAD_UNROLL 4   // windows in flight per thread: the passes are latency bound otherwise
+
+// Work split: workgroup = (sensor chunk, batch part).  Lane group `slot` owns ONE sensor
+// n = chunk*SLOTS + slot and walks the windows of the part, so the embedding row and the
+// embedding-gradient accumulator of (n, columns) live in registers.
 template <int D, int MODE>
 __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   using G = HG<D>;
-  extern __shared__ double smem_d[];
-  double* red = smem_d;                                       // [SLOTS][D] = 1024 doubles
-  float* demb_l = reinterpret_cast<float*>(smem_d + 1024);    // [n][D] (H_BWD1, when it fits)
+  constexpr int U = GDN_HEAD_UNROLL;
+  __shared__ double red[1024];                                // [SLOTS][D]
   const int tid = threadIdx.x, lr = tid % G::LPR, slot = tid / G::LPR, c0 = lr * 4;
   const double rows = (double)a.batch * (double)a.n;
+  const int chunk = blockIdx.x % a.chunks, part = blockIdx.x / a.chunks;
+  const int n = chunk * G::SLOTS + slot;
+  const bool live = n < a.n;
+  const int b0 = (int)((long long)a.batch * part / a.parts);
+  const int b1 = (int)((long long)a.batch * (part + 1) / a.parts);
+
+  // totals of the accumulators earlier passes left behind (summed over their replicas once per workgroup):
+  // rows 0-3 = column sums of z, z^2, h1, h1^2; rows 4-7 = sums of d_y2, d_y2*xhat2, d_y1, d_y1*xhat1
+  __shared__ double tot[8 * D];
+  constexpr int NF = MODE >= H_OUT ? 4 : (MODE >= H_STAT2 ? 2 : 0);
+  constexpr int NB = MODE == H_DZ ? 4 : (MODE == H_BWD1 ? 2 : 0);
+  for (int t = tid; t < NF * D; t += 256) tot[t] = repl_sum(a.fstats + t, 4 * D);
+  for (int t = tid; t < NB * D; t += 256) tot[4 * D + t] = repl_sum(a.acc + t, 6 * D);
+  if constexpr (NF > 0) __syncthreads();
 
   BnCols bn1 = {}, bn2 = {};
-  if constexpr (MODE >= H_STAT2) bn1 = bn_cols(a.fstats, a.fstats + D, rows, a.eps1, a.g1, a.b1, c0);
-  if constexpr (MODE >= H_OUT) bn2 = bn_cols(a.fstats + 2 * D, a.fstats + 3 * D, rows, a.eps2, a.g2, a.b2, c0);
+  if constexpr (MODE >= H_STAT2) bn1 = bn_cols(tot, tot + D, rows, a.eps1, a.g1, a.b1, c0);
+  if constexpr (MODE >= H_OUT) bn2 = bn_cols(tot + 2 * D, tot + 3 * D, rows, a.eps2, a.g2, a.b2, c0);
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
   if constexpr (MODE >= H_OUT) ld4(a.w + c0, w4);
   float m2a[4] = {}, m2b[4] = {}, m1a[4] = {}, m1b[4] = {};
   if constexpr (MODE >= H_BWD1) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      m2a[v] = (float)(a.acc[c0 + v] / rows);           // mean of d_y2
-      m2b[v] = (float)(a.acc[D + c0 + v] / rows);       // mean of d_y2 * xhat2
+      m2a[v] = (float)(tot[4 * D + c0 + v] / rows);     // mean of d_y2
+      m2b[v] = (float)(tot[5 * D + c0 + v] / rows);     // mean of d_y2 * xhat2
     }
   }
   if constexpr (MODE == H_DZ) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      m1a[v] = (float)(a.acc[2 * D + c0 + v] / rows);
-      m1b[v] = (float)(a.acc[3 * D + c0 + v] / rows);
+      m1a[v] = (float)(tot[6 * D + c0 + v] / rows);
+      m1b[v] = (float)(tot[7 * D + c0 + v] / rows);
     }
   }
   double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
   double acc_s = 0.0;
-  if constexpr (MODE == H_BWD1) {
-    if (a.demb_lds) {
-      for (int t = tid; t < a.n * D; t += 256) demb_l[t] = 0.f;
-      __syncthreads();
-    }
-  }
   const float bias_o = (MODE == H_OUT) ? a.bo[0] : 0.f;
+  float e[4] = {0.f, 0.f, 0.f, 0.f};
+  if (MODE >= H_STAT2 && live) ld4(a.emb + (size_t)n * D + c0, e);
 
-  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
-    for (int n = slot; n < a.n; n += G::SLOTS) {
-      const size_t off = ((size_t)b * a.n + n) * D + c0;
-      float z[4];
-      ld4(a.z + off, z);
-      if constexpr (MODE == H_STAT1) {
+  if (live) {
+    for (int bq = b0; bq < b1; bq += U) {
+      float zq[U][4], mq[U][4], goq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                     // all loads of the round first
+        const int b = min(bq + u, b1 - 1);
+        const size_t row = (size_t)b * a.n + n;
+        ld4(a.z + row * D + c0, zq[u]);
+        mq[u][0] = mq[u][1] = mq[u][2] = mq[u][3] = 1.f;
+        if (MODE >= H_OUT && a.mask) ld4(a.mask + row * D + c0, mq[u]);
+        goq[u] = MODE >= H_BWD2 ? a.d_out[row] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (bq + u >= b1) break;
+        const size_t row = (size_t)(bq + u) * a.n + n;
+        const float(&z)[4] = zq[u];
+        const float(&m)[4] = mq[u];
+        if constexpr (MODE == H_STAT1) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const double zd = (double)z[v];
+            acc0[v] += zd;
+            acc1[v] = fma(zd, zd, acc1[v]);
+          }
+          continue;
+        }
+        float y1[4], a1[4], h1[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const double zd = (double)z[v];
-          acc0[v] += zd;
-          acc1[v] = fma(zd, zd, acc1[v]);
+          y1[v] = fmaf(z[v] - bn1.mu[v], bn1.sc[v], bn1.be[v]);
+          a1[v] = fmaxf(y1[v], 0.f);
+          h1[v] = a1[v] * e[v];
         }
-        continue;
-      }
-      float e[4], y1[4], a1[4], h1[4];
-      ld4(a.emb + (size_t)n * D + c0, e);
+        if constexpr (MODE == H_STAT2) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        y1[v] = fmaf(z[v] - bn1.mu[v], bn1.sc[v], bn1.be[v]);
-        a1[v] = fmaxf(y1[v], 0.f);
-        h1[v] = a1[v] * e[v];
-      }
-      if constexpr (MODE == H_STAT2) {
+          for (int v = 0; v < 4; ++v) {
+            const double hd = (double)h1[v];
+            acc0[v] += hd;
+            acc1[v] = fma(hd, hd, acc1[v]);
+          }
+          continue;
+        }
+        float y2[4], a2[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const double hd = (double)h1[v];
-          acc0[v] += hd;
-          acc1[v] = fma(hd, hd, acc1[v]);
+          y2[v] = fmaf(h1[v] - bn2.mu[v], bn2.sc[v], bn2.be[v]);
+          a2[v] = fmaxf(y2[v], 0.f);
         }
-        continue;
-      }
-      float y2[4], a2[4], m[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.mask) ld4(a.mask + off, m);
+        if constexpr (MODE == H_OUT) {
+          float part_o = 0.f;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        y2[v] = fmaf(h1[v] - bn2.mu[v], bn2.sc[v], bn2.be[v]);
-        a2[v] = fmaxf(y2[v], 0.f);
-      }
-      if constexpr (MODE == H_OUT) {
-        float part = 0.f;
+          for (int v = 0; v < 4; ++v) part_o = fmaf(a2[v] * m[v], w4[v], part_o);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) part = fmaf(a2[v] * m[v], w4[v], part);
-#pragma unroll
-        for (int s = 1; s < G::LPR; s <<= 1) part += __shfl_xor(part, s);
-        if (lr == 0) a.out[(size_t)b * a.n + n] = part + bias_o;
-        continue;
-      }
-      const float go = a.d_out[(size_t)b * a.n + n];
-      float dy2[4], x2h[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        dy2[v] = y2[v] > 0.f ? go * w4[v] * m[v] : 0.f;
-        x2h[v] = (h1[v] - bn2.mu[v]) * bn2.is[v];
-      }
-      if constexpr (MODE == H_BWD2) {
+          for (int s = 1; s < G::LPR; s <<= 1) part_o += __shfl_xor(part_o, s);   // lanes of one row
+          if (lr == 0) a.out[row] = part_o + bias_o;
+          continue;
+        }
+        const float go = goq[u];
+        float dy2[4], x2h[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          acc0[v] += (double)dy2[v];
-          acc1[v] += (double)(dy2[v] * x2h[v]);
-          acc2[v] += (double)(go * a2[v] * m[v]);
+          dy2[v] = y2[v] > 0.f ? go * w4[v] * m[v] : 0.f;
+          x2h[v] = (h1[v] - bn2.mu[v]) * bn2.is[v];
         }
-        if (lr == 0) acc_s += (double)go;
-        continue;
-      }
-      float dh1[4], dy1[4], x1h[4];
+        if constexpr (MODE == H_BWD2) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        dh1[v] = bn2.sc[v] * (dy2[v] - m2a[v] - x2h[v] * m2b[v]);
-        dy1[v] = y1[v] > 0.f ? dh1[v] * e[v] : 0.f;
-        x1h[v] = (z[v] - bn1.mu[v]) * bn1.is[v];
-      }
-      if constexpr (MODE == H_BWD1) {
+          for (int v = 0; v < 4; ++v) {
+            acc0[v] += (double)dy2[v];
+            acc1[v] += (double)(dy2[v] * x2h[v]);
+            acc2[v] += (double)(go * a2[v] * m[v]);
+          }
+          if (lr == 0) acc_s += (double)go;
+          continue;
+        }
+        float dh1[4], dy1[4], x1h[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          acc0[v] += (double)dy1[v];
-          acc1[v] += (double)(dy1[v] * x1h[v]);
-          const float de = dh1[v] * a1[v];
-          if (a.demb_lds) demb_l[n * D + c0 + v] += de;       // (n, column) is private to this thread
-          else atomicAdd(a.acc + 6 * D + (size_t)n * D + c0 + v, (double)de);
+          dh1[v] = bn2.sc[v] * (dy2[v] - m2a[v] - x2h[v] * m2b[v]);
+          dy1[v] = y1[v] > 0.f ? dh1[v] * e[v] : 0.f;
+          x1h[v] = (z[v] - bn1.mu[v]) * bn1.is[v];
         }
-        continue;
-      }
-      if constexpr (MODE == H_DZ) {
-        float4 o;
-        o.x = bn1.sc[0] * (dy1[0] - m1a[0] - x1h[0] * m1b[0]);
-        o.y = bn1.sc[1] * (dy1[1] - m1a[1] - x1h[1] * m1b[1]);
-        o.z = bn1.sc[2] * (dy1[2] - m1a[2] - x1h[2] * m1b[2]);
-        o.w = bn1.sc[3] * (dy1[3] - m1a[3] - x1h[3] * m1b[3]);
-        *reinterpret_cast<float4*>(a.d_z + off) = o;
+        if constexpr (MODE == H_BWD1) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            acc0[v] += (double)dy1[v];
+            acc1[v] += (double)(dy1[v] * x1h[v]);
+            acc2[v] += (double)(dh1[v] * a1[v]);        // d_emb[n, column]: private to this thread
+          }
+          continue;
+        }
+        if constexpr (MODE == H_DZ) {
+          float4 o;
+          o.x = bn1.sc[0] * (dy1[0] - m1a[0] - x1h[0] * m1b[0]);
+          o.y = bn1.sc[1] * (dy1[1] - m1a[1] - x1h[1] * m1b[1]);
+          o.z = bn1.sc[2] * (dy1[2] - m1a[2] - x1h[2] * m1b[2]);
+          o.w = bn1.sc[3] * (dy1[3] - m1a[3] - x1h[3] * m1b[3]);
+          *reinterpret_cast<float4*>(a.d_z + row * D + c0) = o;
+        }
       }
     }
   }
 
+  const int repl = blockIdx.x % GDN_HEAD_REPL;
   if constexpr (MODE == H_STAT1 || MODE == H_STAT2) {
-    double* dst = a.acc + (MODE == H_STAT1 ? 0 : 2 * D);
+    double* dst = a.acc + (size_t)repl * 4 * D + (MODE == H_STAT1 ? 0 : 2 * D);
     col_reduce<D>(acc0, red, dst, tid, slot, c0);
     col_reduce<D>(acc1, red, dst + D, tid, slot, c0);
   }
   if constexpr (MODE == H_BWD2) {
-    col_reduce<D>(acc0, red, a.acc, tid, slot, c0);
-    col_reduce<D>(acc1, red, a.acc + D, tid, slot, c0);
-    col_reduce<D>(acc2, red, a.acc + 4 * D, tid, slot, c0);
+    double* dst = a.acc + (size_t)repl * 6 * D;
+    col_reduce<D>(acc0, red, dst, tid, slot, c0);
+    col_reduce<D>(acc1, red, dst + D, tid, slot, c0);
+    col_reduce<D>(acc2, red, dst + 4 * D, tid, slot, c0);
     __syncthreads();
     red[tid] = acc_s;
     __syncthreads();
     if (tid == 0) {
       double s = 0.0;
       for (int q = 0; q < 256; ++q) s += red[q];
-      atomicAdd(a.acc + 5 * D, s);
+      atomicAdd(dst + 5 * D, s);
     }
   }
   if constexpr (MODE == H_BWD1) {
-    col_reduce<D>(acc0, red, a.acc + 2 * D, tid, slot, c0);
-    col_reduce<D>(acc1, red, a.acc + 3 * D, tid, slot, c0);
-    if (a.demb_lds) {
-      __syncthreads();
-      for (int t = tid; t < a.n * D; t += 256) atomicAdd(a.acc + 6 * D + t, (double)demb_l[t]);
-    }
+    double* dst = a.acc + (size_t)repl * 6 * D;
+    col_reduce<D>(acc0, red, dst + 2 * D, tid, slot, c0);
+    col_reduce<D>(acc1, red, dst + 3 * D, tid, slot, c0);
+    if (live)   // every (part, sensor, column) has exactly one owner: plain store, summed by the finish kernel
+      *reinterpret_cast<float4*>(a.demb_part + ((size_t)part * a.n + n) * D + c0) =
+          make_float4((float)acc2[0], (float)acc2[1], (float)acc2[2], (float)acc2[3]);
   }
 }
 
@@ -255,8 +294,8 @@ __global__ void gdn_head_running_kernel(const double* __restrict__ fstats, doubl
       const float mom = which ? mom2 : mom1;
       if (!rm || !rv) continue;
       const double* s = fstats + which * 2 * d;
-      const double m = s[t] / rows;
-      double var = s[d + t] / rows - m * m;
+      const double m = repl_sum(s + t, 4 * d) / rows;
+      double var = repl_sum(s + d + t, 4 * d) / rows - m * m;
       if (var < 0.0) var = 0.0;
       const double unbiased = var * rows / (rows - 1.0);
       rm[t] = (1.f - mom) * rm[t] + mom * (float)m;
@@ -269,40 +308,41 @@ __global__ void gdn_head_running_kernel(const double* __restrict__ fstats, doubl
   }
 }
 
-__global__ void gdn_head_finish_kernel(const double* __restrict__ ws, int n, int d, float* d_bn1_w,
-                                       float* d_bn1_b, float* d_bn2_w, float* d_bn2_b, float* d_lin_w,
-                                       float* d_lin_b, float* d_emb) {
+__global__ void gdn_head_finish_kernel(const double* __restrict__ ws, const float* __restrict__ demb_part,
+                                       int parts, int n, int d, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
+                                       float* d_bn2_b, float* d_lin_w, float* d_lin_b, float* d_emb) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < d) {
-    d_bn2_b[t] = (float)ws[t];
-    d_bn2_w[t] = (float)ws[d + t];
-    d_bn1_b[t] = (float)ws[2 * d + t];
-    d_bn1_w[t] = (float)ws[3 * d + t];
-    d_lin_w[t] = (float)ws[4 * d + t];
-    if (t == 0) d_lin_b[0] = (float)ws[5 * d];
+    d_bn2_b[t] = (float)repl_sum(ws + t, 6 * d);
+    d_bn2_w[t] = (float)repl_sum(ws + d + t, 6 * d);
+    d_bn1_b[t] = (float)repl_sum(ws + 2 * d + t, 6 * d);
+    d_bn1_w[t] = (float)repl_sum(ws + 3 * d + t, 6 * d);
+    d_lin_w[t] = (float)repl_sum(ws + 4 * d + t, 6 * d);
+    if (t == 0) d_lin_b[0] = (float)repl_sum(ws + 5 * d, 6 * d);
   }
-  if (t < n * d) d_emb[t] = (float)ws[6 * d + t];
+  if (t < n * d) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int p = 0; p < parts; ++p) s += (double)demb_part[(size_t)p * n * d + t];
+    d_emb[t] = (float)s;
+  }
 }
 
-int head_grid(int batch) {
-  const int cap = 4 * gdn_cu_count();
-  return batch < cap ? batch : cap;
+int head_parts(int batch, int chunks, int mode) {
+  // reduction passes: ~2 workgroups per CU (fewer atomics); streaming passes: ~4
+  const int target = (mode == H_OUT || mode == H_DZ ? 4 : 2) * gdn_cu_count();
+  int parts = (target + chunks - 1) / chunks;
+  const int by_rounds = (batch + GDN_HEAD_UNROLL - 1) / GDN_HEAD_UNROLL;   // at least one full round each
+  if (parts > by_rounds) parts = by_rounds;
+  if (mode == H_BWD1 && parts > GDN_HEAD_EMB_PARTS) parts = GDN_HEAD_EMB_PARTS;
+  return parts < 1 ? 1 : parts;
 }
 
 template <int D, int MODE>
-void launch_pass(const HeadArgs& a, hipStream_t st) {
-  size_t lds = 1024 * sizeof(double);
-  if (MODE == H_BWD1 && a.demb_lds) lds += (size_t)a.n * D * sizeof(float);
-  if (lds > 64 * 1024) {
-    static bool raised = false;   // per instantiation: allow more than the default 64 KB of dynamic LDS
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gdn_head_train_kernel<D, MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        (void)hipGetLastError();
-      raised = true;
-    }
-  }
-  hipLaunchKernelGGL((gdn_head_train_kernel<D, MODE>), dim3(head_grid(a.batch)), dim3(256), lds, st, a);
+void launch_pass(HeadArgs a, hipStream_t st) {
+  a.chunks = (a.n + HG<D>::SLOTS - 1) / HG<D>::SLOTS;
+  a.parts = head_parts(a.batch, a.chunks, MODE);
+  hipLaunchKernelGGL((gdn_head_train_kernel<D, MODE>), dim3(a.chunks * a.parts), dim3(256), 0, st, a);
 }
 
 bool head_shape_ok(int batch, int n, int d) {
@@ -311,9 +351,14 @@ bool head_shape_ok(int batch, int n, int d) {
 
 }  // namespace
 
+extern "C" long long gdn_head_train_stats_bytes(int d) {
+  return d <= 0 ? 0 : (long long)GDN_HEAD_REPL * 4 * d * (long long)sizeof(double);
+}
+
 extern "C" long long gdn_head_train_workspace_bytes(int n, int d) {
   if (n <= 0 || d <= 0) return 0;
-  return (long long)(6LL * d + (long long)n * d) * (long long)sizeof(double);
+  return (long long)GDN_HEAD_REPL * 6 * d * (long long)sizeof(double) +
+         (long long)GDN_HEAD_EMB_PARTS * n * d * (long long)sizeof(float);
 }
 
 extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
@@ -332,7 +377,8 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = lin_b;
   a.mask = mask; a.fstats = stats; a.acc = stats; a.out = out; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
-  if (hipMemsetAsync(stats, 0, 4 * (size_t)d * sizeof(double), st) != hipSuccess) return GDN_ERR_LAUNCH;
+  if (hipMemsetAsync(stats, 0, (size_t)GDN_HEAD_REPL * 4 * d * sizeof(double), st) != hipSuccess)
+    return GDN_ERR_LAUNCH;
 #define GDN_HEAD_F(DD)                 \
   case DD:                             \
     launch_pass<DD, H_STAT1>(a, st);   \
@@ -369,9 +415,9 @@ extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const floa
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = nullptr;
   a.mask = mask; a.d_out = d_out; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
-  a.demb_lds = ((size_t)n * d * sizeof(float) + 1024 * sizeof(double)) <= 160 * 1024 ? 1 : 0;
-  if (hipMemsetAsync(workspace, 0, (size_t)gdn_head_train_workspace_bytes(n, d), st) != hipSuccess)
-    return GDN_ERR_LAUNCH;
+  const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
+  a.demb_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sums_bytes);
+  if (hipMemsetAsync(workspace, 0, sums_bytes, st) != hipSuccess) return GDN_ERR_LAUNCH;
 #define GDN_HEAD_B(DD)                \
   case DD:                            \
     launch_pass<DD, H_BWD2>(a, st);   \
@@ -386,7 +432,8 @@ extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const floa
   }
 #undef GDN_HEAD_B
   const int total = n * d > d ? n * d : d;
-  hipLaunchKernelGGL(gdn_head_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, n, d,
-                     d_bn1_w, d_bn1_b, d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, d_emb);
+  const int chunks = (n + 256 / (d / 4) - 1) / (256 / (d / 4));
+  hipLaunchKernelGGL(gdn_head_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace,
+                     a.demb_part, head_parts(batch, chunks, H_BWD1), n, d, d_bn1_w, d_bn1_b, d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, d_emb);
   return gdn_launch_status();
 }

@@ -357,14 +357,16 @@ class GraphedTrainStep:
         self.x = torch.zeros((batch, n, w), dtype=torch.float32, device=dev)
         self.y = torch.zeros((batch, n), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True)
+        # fused: one multi-tensor launch for all 13 parameters instead of ~40 small ones
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True,
+                                          fused=True)
         self.use_graph = use_graph
         self._graphs = None
         self._split = world()[1] > 1
 
     # the two halves of a step; `loss` is written in place so it survives replays
     def _forward_backward(self):
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad(set_to_none=True)      # backward then writes fresh gradients: no fill, no add
         out = self.model(self.x, None)
         loss = F.mse_loss(out, self.y, reduction="mean")
         loss.backward()

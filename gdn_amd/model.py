@@ -73,8 +73,7 @@ class _GraphAttentionFn(torch.autograd.Function):
     (reference models/graph_layer.py:53-117 and the autograd graph behind train.py:72)."""
 
     @staticmethod
-    def forward(ctx, x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, bias, graph, batch):
-        terms = ops.node_terms(lin_w, att_i, att_j, att_em_i, att_em_j, emb)
+    def forward(ctx, x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, bias, graph, batch, terms):
         xlin, s_i, s_j = ops.project_fwd(x, lin_w, terms)
         z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, graph, bias, batch, want_alpha=True)
         ctx.save_for_backward(x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, xlin, s_i, s_j, alpha)
@@ -88,16 +87,9 @@ class _GraphAttentionFn(torch.autograd.Function):
         d_xlin, d_si, d_sj, d_bias = ops.attn_aggregate_bwd(d_z.contiguous(), xlin, alpha, s_i, s_j,
                                                             ctx.graph, ctx.batch)
         d_lin_w, d_a, d_c = ops.project_bwd(x, d_xlin, d_si, d_sj, lin_w.shape[0])
-        w = lin_w.shape[1]
-        # chain rule through the folded constants  a = lin^T att,  c = emb att_em  (tiny [d,w] / [n,d])
-        ai, aj = att_i.reshape(-1), att_j.reshape(-1)
-        d_lin_w = d_lin_w + torch.outer(ai, d_a[0, :w]) + torch.outer(aj, d_a[1, :w])
-        d_att_i = (lin_w @ d_a[0, :w]).view_as(att_i)
-        d_att_j = (lin_w @ d_a[1, :w]).view_as(att_j)
-        d_att_em_i = (emb.t() @ d_c[0]).view_as(att_em_i)
-        d_att_em_j = (emb.t() @ d_c[1]).view_as(att_em_j)
-        d_emb = torch.outer(d_c[0], att_em_i.reshape(-1)) + torch.outer(d_c[1], att_em_j.reshape(-1))
-        return None, d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb, d_bias, None, None
+        d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb = ops.terms_bwd(
+            lin_w, att_i, att_j, att_em_i, att_em_j, emb, d_lin_w, d_a, d_c)
+        return None, d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb, d_bias, None, None, None
 
 
 class _HeadTrainFn(torch.autograd.Function):
@@ -239,7 +231,12 @@ class GDN(nn.Module):
         # .to(device) / .float() replace the parameter storage: forget cached tensors and constants
         self._key_tensors = None
         self._consts = None
+        self._ones = None
         return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_constants(self):
+        """Forget the cached sensor graph / folded constants (see `_constants`)."""
+        self._consts = None
 
     def _param_key(self):
         ps = getattr(self, "_key_tensors", None)
@@ -251,10 +248,14 @@ class GDN(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in ps) + (self.training, inj)
 
     def _constants(self) -> _EvalConstants:
-        """Sensor graph + folded per-forward constants; rebuilt only when a parameter changed."""
+        """Sensor graph + folded per-forward constants.  In eval they are cached and rebuilt when a
+        parameter's (storage, version) changed; in training they are rebuilt every forward — an
+        optimizer step changes the embedding, and fused optimizers (`Adam(fused=True)`) and writes
+        through `.data` do not bump the version counter.  After such a write in eval mode call
+        `invalidate_constants()`."""
         key = self._param_key()
         c = self._consts
-        if c is not None and c.key == key:
+        if c is not None and c.key == key and not self.training:
             return c
         gnn = self.gnn_layers[0].gnn
         c = _EvalConstants()
@@ -326,7 +327,7 @@ class GDN(nn.Module):
 
         # ---- training: HIP forward/backward for the graph layer, torch for BN statistics etc.
         z, alpha = _GraphAttentionFn.apply(x, gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i,
-                                           gnn.att_em_j, emb, gnn.bias, c.graph, batch)
+                                           gnn.att_em_j, emb, gnn.bias, c.graph, batch, c.terms)
         layer._set_dense((alpha, c.graph, batch))
         if self.out_layer_num == 1 and self._hip_train_head_ok():
             lin = self.out_layer.mlp[0]
@@ -352,7 +353,10 @@ class GDN(nn.Module):
         dp = self.dp
         if not dp.training or (isinstance(dp, nn.Dropout) and dp.p == 0):
             return None
-        ones = torch.ones((batch, node_num, d), dtype=torch.float32, device=device)
+        ones = getattr(self, "_ones", None)
+        if ones is None or ones.shape != (batch, node_num, d) or ones.device != device or getattr(dp, "inplace", False):
+            ones = torch.ones((batch, node_num, d), dtype=torch.float32, device=device)
+            self._ones = None if getattr(dp, "inplace", False) else ones
         return dp(ones).reshape(batch * node_num, d)
 
     def forward_into(self, data, out):

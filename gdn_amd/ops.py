@@ -148,7 +148,7 @@ def head_train_fwd(z, emb, bn1, bn2, lin_w, lin_b, mask, batch: int):
     bn, d = z.shape
     n = bn // batch
     out = torch.empty((batch, n), dtype=torch.float32, device=z.device)
-    stats = torch.empty((4 * d,), dtype=torch.float64, device=z.device)
+    stats = torch.empty((_lib.load().gdn_head_train_stats_bytes(d) // 8,), dtype=torch.float64, device=z.device)
     if mask is not None:
         mask = _chk(mask, name="dropout mask")
         if mask.numel() != z.numel():
@@ -242,6 +242,20 @@ def project_bwd(x, d_xlin, d_si, d_sj, d: int):
     _lib.call("gdn_project_bwd", _ptr(x), _ptr(_chk(d_xlin)), _ptr(_chk(d_si)), _ptr(_chk(d_sj)),
               b, n, w, d, _ptr(d_lin_w), _ptr(d_a), _ptr(d_c), _stream())
     return d_lin_w, d_a, d_c
+
+
+def terms_bwd(lin_w, att_i, att_j, att_em_i, att_em_j, emb, d_lin_w, d_a, d_c):
+    """Chain rule through node_terms; d_lin_w (the direct term from project_bwd) is completed in place.
+    Returns (d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb)."""
+    d, w = lin_w.shape
+    n = emb.shape[0]
+    small = torch.empty((4 * d,), dtype=torch.float32, device=emb.device)
+    d_emb = torch.empty((n, d), dtype=torch.float32, device=emb.device)
+    _lib.call("gdn_terms_bwd", _ptr(_chk(lin_w)), _ptr(_chk(att_i)), _ptr(_chk(att_j)), _ptr(_chk(att_em_i)),
+              _ptr(_chk(att_em_j)), _ptr(_chk(emb)), _ptr(d_a), _ptr(d_c), n, d, w, _ptr(d_lin_w),
+              _ptr(small), _ptr(small[d:]), _ptr(small[2 * d:]), _ptr(small[3 * d:]), _ptr(d_emb), _stream())
+    return (d_lin_w, small[:d].view_as(att_i), small[d:2 * d].view_as(att_j), small[2 * d:3 * d].view_as(att_em_i),
+            small[3 * d:].view_as(att_em_j), d_emb)
 
 
 def score_workspace(t: int, n: int, device) -> torch.Tensor:

@@ -110,9 +110,11 @@ int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
  * bn_outlayer_in — biased variance over all batch*n rows) and update running_mean /
  * running_var (momentum, unbiased variance) / num_batches_tracked; dropout (:182) is applied
  * as the caller's mask[BN,d] (0 or 1/(1-p); NULL = no dropout); OutLayer Linear(d->1).
- *   stats[4*d] double (out)  column sums of z, z^2, h1, h1^2 — kept for the backward.
+ *   stats (out)  gdn_head_train_stats_bytes(d) bytes: replicated fp64 column sums of z, z^2,
+ *                h1, h1^2 — opaque, kept for the backward.
  *   running_* / batches*     may be NULL (track_running_stats off).
  * Three streaming passes over z; nothing [BN,d]-sized is stored.  batch*n >= 2.             */
+long long gdn_head_train_stats_bytes(int d);
 int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
                        const float* bn2_w, const float* bn2_b, const float* lin_w,
                        const float* lin_b, const float* mask, int batch, int n, int d,
@@ -181,6 +183,17 @@ int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n, int k,
 int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
                     int batch, int n, int w, int d,
                     float* d_lin_w, float* d_a, float* d_c, void* stream);
+
+/* gdn_terms_bwd: chain rule through gdn_node_terms (a = lin^T att, c = emb . att_em — the
+ * separable form of models/graph_layer.py:90-104): from gdn_project_bwd's d_a[2,64] / d_c[2,n]
+ *   d_lin_w[d,w] += att_i (x) d_a[0] + att_j (x) d_a[1]      (in/out: holds the direct term)
+ *   d_att_i/j[d]  = lin_w d_a[0/1]     d_att_em_i/j[d] = emb^T d_c[0/1]
+ *   d_emb[n,d]    = d_c[0] (x) att_em_i + d_c[1] (x) att_em_j                               */
+int gdn_terms_bwd(const float* lin_w, const float* att_i, const float* att_j,
+                  const float* att_em_i, const float* att_em_j, const float* emb,
+                  const float* d_a, const float* d_c, int n, int d, int w, float* d_lin_w,
+                  float* d_att_i, float* d_att_j, float* d_att_em_i, float* d_att_em_j,
+                  float* d_emb, void* stream);
 
 /* ---- anomaly scoring -----------------------------------------------------------------
  * evaluate.py:48-68 + util/data.py:75-82 + the max over sensors of evaluate.py:131-139,

@@ -181,3 +181,25 @@ def test_graphed_train_step_equals_eager_steps(gpu_device):
         tol = 4.5e-3 if name.endswith("gnn.bias") else 2e-5
         np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), atol=tol, err_msg=name)
     assert min(finals[1][0]) < finals[1][0][0]          # it trains
+
+
+def test_training_forward_follows_unversioned_parameter_writes(gpu_device):
+    """Fused optimizers update parameters without bumping `_version`: the train-mode forward must still
+    rebuild the sensor graph from the current embedding."""
+    from test_gpu_forward_parity import random_params
+    model = random_params(12, 6, 3, 64, seed=1).to(gpu_device).train()
+    x = torch.rand((4, 12, 6), device=gpu_device)
+    model(x, None)
+    before = model.learned_graph.clone()
+    with torch.no_grad():
+        model.embedding.weight.data.copy_(torch.randn_like(model.embedding.weight))   # no version bump
+    model(x, None)
+    assert not torch.equal(before, model.learned_graph)
+    model.eval()
+    model(x, None)
+    cached = model.learned_graph.clone()
+    with torch.no_grad():
+        model.embedding.weight.data.copy_(torch.randn_like(model.embedding.weight))
+    model.invalidate_constants()
+    model(x, None)
+    assert not torch.equal(cached, model.learned_graph)
