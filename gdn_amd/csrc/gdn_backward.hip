@@ -13,7 +13,10 @@
 //     d_xlin[j]  = sum_(i,p) alpha_ip * d_z_i ;  d_s_j[j] = sum_(i,p) d_pi_ip
 // Results are bitwise reproducible (fixed list order); the first version scattered with ds_add_f32
 // and spent 650 us per 512 windows where the forward needs 17.
+#include <stdlib.h>
+
 #include "gdn_common.hpp"
+
 
 namespace {
 
@@ -94,25 +97,31 @@ __device__ __forceinline__ void axpy_steps(const char* tile_lane, float a, int r
 
 struct BwdPlan {
   int n, d, k, pitch, rpitch, batch;
-  int off_tile, off_sj, off_al, off_dpi, off_dbias;  // float offsets
+  int off_tile, off_sj, off_si, off_al, off_dpi, off_dbias, off_nbr;  // float offsets
   int lds_bytes;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void gdn_attn_bwd_kernel(
+// NT threads per workgroup: 512 (8 waves, 4 per SIMD with two workgroups per CU) hides the LDS / DPP
+// latency chains of the two gather loops better than 256; BL = targets / sources a lane group
+// prefetches for before it starts computing (fewer at 512 threads: 128 VGPRs per lane).
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     const BwdPlan pl, const float* __restrict__ d_z, const float* __restrict__ xlin,
     const float* __restrict__ alpha, const float* __restrict__ s_i, const float* __restrict__ s_j,
     const uint16_t* __restrict__ nbr, const uint32_t* __restrict__ rent, const int32_t* __restrict__ rlen,
     float* __restrict__ d_xlin, float* __restrict__ d_si, float* __restrict__ d_sj,
     float* __restrict__ d_bias) {
   using G = GeoB<D>;
+  constexpr int BL = 2048 / NT;
   extern __shared__ float4 smem_b4[];
   float* smem = reinterpret_cast<float*>(smem_b4);
   float* tile = smem + pl.off_tile;    // xlin (pass 1) then d_z (pass 2); row n stays 0
   float* sj = smem + pl.off_sj;
+  float* si = smem + pl.off_si;
   float* al_t = smem + pl.off_al;      // alpha  [n, pitch]
-  float* dpi_t = smem + pl.off_dpi;    // d_pi   [n, pitch]
+  float* dpi_t = smem + pl.off_dpi;    // d_alpha, then d_pi   [n, pitch]
   float* dbias = smem + pl.off_dbias;
+  uint16_t* nb_l = reinterpret_cast<uint16_t*>(smem + pl.off_nbr);   // neighbour lists [n, pitch]
   const int tid = threadIdx.x, nth = blockDim.x;
   const int grp = tid >> 4, l16 = tid & 15;
   const int slot = grp / G::NS, slice = grp % G::NS;
@@ -120,12 +129,15 @@ __global__ __launch_bounds__(256) void gdn_attn_bwd_kernel(
   const int d0 = slice * 64 + l16 * G::VEC;
   const char* tile_lane = reinterpret_cast<const char*>(tile + d0);
   const int rounds = pl.pitch >> 4;
+  const int npl = pl.n * pl.pitch;
 
   for (int t = tid; t < D; t += nth) {
     dbias[t] = 0.f;
     tile[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
   }
   if (tid == 0) sj[pl.n] = 0.f;
+  for (int t = tid; t < npl / 2; t += nth)   // pitch is a multiple of 16: copy the lists as u32 pairs
+    reinterpret_cast<uint32_t*>(nb_l)[t] = reinterpret_cast<const uint32_t*>(nbr)[t];
   PackB<G::VEC> bias_acc;
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] = 0.f;
@@ -133,81 +145,107 @@ __global__ __launch_bounds__(256) void gdn_attn_bwd_kernel(
 
   for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
     const size_t row0 = (size_t)b * pl.n;
-    {
+    {   // bulk staging (many loads in flight): xlin tile, alpha table, s_i, s_j
       const float4* src = reinterpret_cast<const float4*>(xlin + row0 * D);
       float4* dst = reinterpret_cast<float4*>(tile);
+#pragma unroll 4
       for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
-      for (int t = tid; t < pl.n; t += nth) sj[t] = s_j[row0 + t];
+      const float4* asrc = reinterpret_cast<const float4*>(alpha + row0 * pl.pitch);
+      float4* adst = reinterpret_cast<float4*>(al_t);
+#pragma unroll 4
+      for (int t = tid; t < npl / 4; t += nth) adst[t] = asrc[t];
+      for (int t = tid; t < pl.n; t += nth) {
+        sj[t] = s_j[row0 + t];
+        si[t] = s_i[row0 + t];
+      }
     }
     __syncthreads();
 
-    // ---- pass 1: per target
-    for (int i = slot; i < pl.n; i += tpp) {
-      const uint16_t* nrow = nbr + (size_t)i * pl.pitch;
-      const float* arow = alpha + (row0 + i) * pl.pitch;
-      const PackB<G::VEC> g = ldp<G::VEC>(d_z + (row0 + i) * D + d0);
+    // ---- pass 1: per target, BL targets per lane group at a time (their d_z rows are fetched together)
+    for (int ib = slot; ib < pl.n; ib += tpp * BL) {
+      PackB<G::VEC> gq[BL];
 #pragma unroll
-      for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] += g.v[v];
-      const float sti = s_i[row0 + i];
-      float dot = 0.f;
-      for (int r = 0; r < rounds; ++r) {
-        const int p = r * 16 + l16;
-        const int j = nrow[p];            // padding = sentinel n (zero row, alpha 0)
-        float tsum = 0.f;
-        dot_steps<D>(tile_lane, j * (D * 4), g, tsum);
-        if constexpr (G::NS == 2) tsum += __shfl_xor(tsum, 16);
-        const float al = arow[p];
-        dot = fmaf(al, tsum, dot);
-        if (slice == 0) {
-          al_t[i * pl.pitch + p] = al;
-          dpi_t[i * pl.pitch + p] = tsum;   // d_alpha for now; finished below
-        }
-      }
-      dot = row16_sum(dot);
-      float dsi = 0.f;
-      if (slice == 0) {
+      for (int q = 0; q < BL; ++q)
+        gq[q] = ldp<G::VEC>(d_z + (row0 + min(ib + q * tpp, pl.n - 1)) * D + d0);
+#pragma unroll
+      for (int q = 0; q < BL; ++q) {
+        const int i = ib + q * tpp;
+        if (i >= pl.n) break;
+        const PackB<G::VEC>& g = gq[q];
+#pragma unroll
+        for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] += g.v[v];
+        const float sti = si[i];
+        float dot = 0.f;
         for (int r = 0; r < rounds; ++r) {
-          const int p = r * 16 + l16;
-          const int j = nrow[p];
-          const float al = al_t[i * pl.pitch + p];      // written by this lane above
-          const float de = al * (dpi_t[i * pl.pitch + p] - dot);
-          const float pi = sti + sj[j];
-          const float dpi = de * (pi > 0.f ? 1.f : GDN_NEG_SLOPE);
-          dpi_t[i * pl.pitch + p] = dpi;
-          dsi += dpi;
+          const int p = i * pl.pitch + r * 16 + l16;
+          const int j = nb_l[p];            // padding = sentinel n (zero row, alpha 0)
+          float tsum = 0.f;
+          dot_steps<D>(tile_lane, j * (D * 4), g, tsum);
+          if constexpr (G::NS == 2) tsum += __shfl_xor(tsum, 16);
+          dot = fmaf(al_t[p], tsum, dot);
+          if (slice == 0) dpi_t[p] = tsum;   // d_alpha for now; finished below
         }
+        dot = row16_sum(dot);
+        float dsi = 0.f;
+        if (slice == 0) {
+          for (int r = 0; r < rounds; ++r) {
+            const int p = i * pl.pitch + r * 16 + l16;
+            const int j = nb_l[p];
+            const float de = al_t[p] * (dpi_t[p] - dot);   // dpi_t[p] written by this lane above
+            const float pi = sti + sj[j];
+            const float dpi = de * (pi > 0.f ? 1.f : GDN_NEG_SLOPE);
+            dpi_t[p] = dpi;
+            dsi += dpi;
+          }
+        }
+        dsi = row16_sum(dsi);
+        if (l16 == 0 && slice == 0) d_si[row0 + i] = dsi;
       }
-      dsi = row16_sum(dsi);
-      if (l16 == 0 && slice == 0) d_si[row0 + i] = dsi;
     }
     __syncthreads();
     {   // the tile now holds d_z of this window (row n stays 0)
       const float4* src = reinterpret_cast<const float4*>(d_z + row0 * D);
       float4* dst = reinterpret_cast<float4*>(tile);
+#pragma unroll 4
       for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
     }
     __syncthreads();
 
-    // ---- pass 2: per source, over its reverse list
-    for (int j = slot; j < pl.n; j += tpp) {
-      const int len = rlen[j];
-      const uint32_t* rrow = rent + (size_t)j * pl.rpitch;
-      PackB<G::VEC> acc;
+    // ---- pass 2: per source, over its reverse list; the first two rounds of BL sources are fetched together
+    for (int jb = slot; jb < pl.n; jb += tpp * BL) {
+      int lenq[BL];
+      uint32_t e0[BL], e1[BL];
 #pragma unroll
-      for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
-      float dsj = 0.f;
-      for (int r0 = 0; r0 < len; r0 += 16) {
-        const int e = r0 + l16;
-        const bool valid = e < len;
-        const uint32_t ent = rrow[valid ? e : 0];
-        const int i = ent >> 16, p = ent & 0xffff;
-        const float a = valid ? al_t[i * pl.pitch + p] : 0.f;
-        dsj += valid ? dpi_t[i * pl.pitch + p] : 0.f;
-        axpy_steps<D>(tile_lane, a, (valid ? i : pl.n) * (D * 4), acc);
+      for (int q = 0; q < BL; ++q) {
+        const int j = min(jb + q * tpp, pl.n - 1);
+        const uint32_t* rrow = rent + (size_t)j * pl.rpitch;
+        lenq[q] = rlen[j];
+        e0[q] = rrow[l16];                                   // rpitch >= 16: always in bounds
+        e1[q] = rrow[pl.rpitch >= 32 ? 16 + l16 : l16];
       }
-      stp<G::VEC>(d_xlin + (row0 + j) * D + d0, acc);
-      dsj = row16_sum(dsj);
-      if (l16 == 0 && slice == 0) d_sj[row0 + j] = dsj;
+#pragma unroll
+      for (int q = 0; q < BL; ++q) {
+        const int j = jb + q * tpp;
+        if (j >= pl.n) break;
+        const int len = lenq[q];
+        const uint32_t* rrow = rent + (size_t)j * pl.rpitch;
+        PackB<G::VEC> acc;
+#pragma unroll
+        for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
+        float dsj = 0.f;
+        for (int r0 = 0; r0 < len; r0 += 16) {
+          const int e = r0 + l16;
+          const bool valid = e < len;
+          const uint32_t ent = r0 == 0 ? e0[q] : (r0 == 16 ? e1[q] : rrow[valid ? e : 0]);
+          const int i = valid ? (int)(ent >> 16) : 0, p = valid ? (int)(ent & 0xffff) : 0;
+          const float a = valid ? al_t[i * pl.pitch + p] : 0.f;
+          dsj += valid ? dpi_t[i * pl.pitch + p] : 0.f;
+          axpy_steps<D>(tile_lane, a, (valid ? i : pl.n) * (D * 4), acc);
+        }
+        stp<G::VEC>(d_xlin + (row0 + j) * D + d0, acc);
+        dsj = row16_sum(dsj);
+        if (l16 == 0 && slice == 0) d_sj[row0 + j] = dsj;
+      }
     }
     __syncthreads();   // tables and tile are rewritten by the next window
   }
@@ -252,92 +290,151 @@ __global__ __launch_bounds__(256) void gdn_graph_reverse_kernel(const uint16_t* 
   if (tid == 0) rlen[j] = base_s;
 }
 
-// d_lin_w[d,w] += sum_rows d_xlin[row,d] x[row,w];  d_a[2,64] += sum_rows d_s[row] x[row,:];
-// d_c[2,n] += sum_b d_s[b*n + s].
-template <int D, int WCH>
+// d_lin_w[d,w] = sum_rows d_xlin[row,d] x[row,w];  d_a[2,64] = sum_rows d_s[row] x[row,:];
+// d_c[2,n] = sum_b d_s[b*n + s].
+//
+// Every output is OWNED by one thread (no reduction across threads, no atomics: an earlier version
+// accumulated 16 lane groups into LDS with ds_add_f32 and spent 2/3 of its time there).  Output
+// o = c*D + d: a thread keeps one d and D/16 columns c in registers across all windows of the
+// workgroup; per staged row it reads d_xlin[row,d] once (consecutive lanes = consecutive d, conflict
+// free) and x[row,c] as an LDS broadcast.  A pass covers 16 columns; w > 16 takes wp/16 passes.
+// Each workgroup ends with ONE partial row [D*wp + 128 + 2n]; gdn_project_reduce_kernel sums the rows.
+template <int D>
 __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
-    int batch, int n, int w, int wp, const float* __restrict__ x, const float* __restrict__ d_xlin,
-    const float* __restrict__ d_si, const float* __restrict__ d_sj, float* __restrict__ d_lin_w,
-    float* __restrict__ d_a, float* __restrict__ d_c) {
-  using G = GeoB<D>;
+    int batch, int n, int w, int wp, int rc, const float* __restrict__ x, const float* __restrict__ d_xlin,
+    const float* __restrict__ d_si, const float* __restrict__ d_sj, float* __restrict__ part) {
+  constexpr int OPT = D / 16;        // outputs per thread and pass
+  constexpr int CSTEP = 256 / D;     // column distance between a thread's outputs
   extern __shared__ float4 smem_b4[];
   float* smem = reinterpret_cast<float*>(smem_b4);
-  float* xs = smem;                 // [n][wp]
-  float* dw = xs + (size_t)n * wp;  // [D][wp] workgroup partial of d_lin_w
-  float* da = dw + (size_t)D * wp;  // [2][64]
-  float* dc = da + 128;             // [2][n]
-  const int tid = threadIdx.x, nth = blockDim.x;
-  const int grp = tid >> 4, l16 = tid & 15;
-  const int slot = grp / G::NS, slice = grp % G::NS;
-  const int tpp = (nth >> 4) / G::NS;
-  const int d0 = slice * 64 + l16 * G::VEC;
-  const int nch = wp / WCH;
+  float* gs = smem;                      // [rc][D]   d_xlin rows of the chunk
+  float* xs = gs + (size_t)rc * D;       // [rc][wp]  x rows, zero padded to wp columns
+  float* ds = xs + (size_t)rc * wp;      // [2][rc]   d_si, d_sj
+  float* dc = ds + 2 * rc;               // [2][n]    sums over this workgroup's windows
+  const int tid = threadIdx.x;
+  const int d = tid % D, cq0 = tid / D;
+  const int nout = D * wp;
+  float* row_out = part + (size_t)blockIdx.x * (nout + 128 + 2 * n);
+  const int a_which = tid >> 6, a_c = tid & 63;          // d_a owner (tid < 128)
+  const bool a_owner = tid < 128 && a_c < wp;
 
-  for (int t = tid; t < D * wp + 128 + 2 * n; t += nth) dw[t] = 0.f;
-  __syncthreads();
+  for (int t = tid; t < 2 * n; t += 256) dc[t] = 0.f;
 
-  // accumulators live in registers across ALL windows of this workgroup and are flushed once per
-  // W-chunk (flushing per window cost 16k ds_add_f32 per window)
-  for (int wc = 0; wc < nch; ++wc) {
-    float acc[G::VEC][WCH];
+  for (int pass = 0; pass * 16 < wp; ++pass) {
+    float acc[OPT];
 #pragma unroll
-    for (int v = 0; v < G::VEC; ++v)
+    for (int q = 0; q < OPT; ++q) acc[q] = 0.f;
+    float acc_a = 0.f;
+    int cidx[OPT];
 #pragma unroll
-      for (int c = 0; c < WCH; ++c) acc[v][c] = 0.f;
-    float ai = 0.f, aj = 0.f;
-    const bool ahas = l16 < WCH;
+    for (int q = 0; q < OPT; ++q) cidx[q] = min(pass * 16 + cq0 + CSTEP * q, wp - 1);   // clamped: never stored
     for (int b = blockIdx.x; b < batch; b += gridDim.x) {
       const size_t row0 = (size_t)b * n;
-      const float* xg = x + row0 * w;
-      for (int t = tid; t < n * wp; t += nth) {
-        const int r = t / wp, c = t - r * wp;
-        xs[t] = c < w ? xg[(size_t)r * w + c] : 0.f;
-      }
-      if (wc == 0) {
-        for (int t = tid; t < n; t += nth) {
-          dc[t] += d_si[row0 + t];
-          dc[n + t] += d_sj[row0 + t];
+      for (int r0 = 0; r0 < n; r0 += rc) {
+        const int rows = min(rc, n - r0);
+        __syncthreads();   // previous chunk fully consumed
+        {
+          // eight unconditional (clamped) loads per thread are issued before the first LDS store, so a
+          // chunk costs one or two HBM round trips instead of one per loop iteration
+          const float4* src = reinterpret_cast<const float4*>(d_xlin + (row0 + r0) * D);
+          float4* dst = reinterpret_cast<float4*>(gs);
+          const int tot4 = rows * D / 4;
+          for (int base = 0; base < tot4; base += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(base + u * 256 + tid, tot4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (base + u * 256 + tid < tot4) dst[base + u * 256 + tid] = v[u];
+          }
+          const float* xg = x + (row0 + r0) * w;
+          const int totx = rows * wp;
+          for (int base = 0; base < totx; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int t = min(base + u * 256 + tid, totx - 1);
+              const int r = t / wp, c = t - r * wp;
+              v[u] = xg[(size_t)r * w + min(c, w - 1)];
+              if (c >= w) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (base + u * 256 + tid < totx) xs[base + u * 256 + tid] = v[u];
+          }
+          for (int t = tid; t < rows; t += 256) {
+            const float a = d_si[row0 + r0 + t], bq = d_sj[row0 + r0 + t];
+            ds[t] = a;
+            ds[rc + t] = bq;
+            if (pass == 0) {
+              dc[r0 + t] += a;
+              dc[n + r0 + t] += bq;
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < rows; ++r) {
+          const float g = gs[r * D + d];
+          const float* xr = xs + r * wp;
+#pragma unroll
+          for (int q = 0; q < OPT; ++q) acc[q] = fmaf(g, xr[cidx[q]], acc[q]);
+        }
+        if (pass == 0 && a_owner) {
+          const float* dsel = ds + a_which * rc;
+#pragma unroll 4
+          for (int r = 0; r < rows; ++r) acc_a = fmaf(dsel[r], xs[r * wp + a_c], acc_a);
         }
       }
-      __syncthreads();
-      for (int row = slot; row < n; row += tpp) {
-        const float* xrow = xs + (size_t)row * wp + wc * WCH;
-        float xr[WCH];
-#pragma unroll
-        for (int c = 0; c < WCH; c += 4) {
-          const float4 t = *reinterpret_cast<const float4*>(xrow + c);
-          xr[c] = t.x; xr[c + 1] = t.y; xr[c + 2] = t.z; xr[c + 3] = t.w;
-        }
-        const PackB<G::VEC> g = ldp<G::VEC>(d_xlin + (row0 + row) * D + d0);
-#pragma unroll
-        for (int v = 0; v < G::VEC; ++v)
-#pragma unroll
-          for (int c = 0; c < WCH; ++c) acc[v][c] = fmaf(g.v[v], xr[c], acc[v][c]);
-        if (slice == 0 && ahas) {
-          const float xv = xrow[l16];
-          ai = fmaf(d_si[row0 + row], xv, ai);
-          aj = fmaf(d_sj[row0 + row], xv, aj);
-        }
-      }
-      __syncthreads();   // the x tile is restaged for the next window
     }
 #pragma unroll
-    for (int v = 0; v < G::VEC; ++v)
-#pragma unroll
-      for (int c = 0; c < WCH; ++c) atomicAdd(&dw[(size_t)(d0 + v) * wp + wc * WCH + c], acc[v][c]);
-    if (slice == 0 && ahas) {
-      atomicAdd(&da[wc * WCH + l16], ai);
-      atomicAdd(&da[64 + wc * WCH + l16], aj);
+    for (int q = 0; q < OPT; ++q) {
+      const int c = pass * 16 + cq0 + CSTEP * q;
+      if (c < wp) row_out[c * D + d] = acc[q];
     }
+    if (pass == 0 && tid < 128) row_out[nout + tid] = a_owner ? acc_a : 0.f;
   }
   __syncthreads();
-  // one flush per workgroup
-  for (int t = tid; t < D * wp; t += nth) {
-    const int r = t / wp, c = t - r * wp;
-    if (c < w) atomicAdd(&d_lin_w[(size_t)r * w + c], dw[t]);
+  for (int t = tid; t < 2 * n; t += 256) row_out[nout + 128 + t] = dc[t];
+}
+
+// out = sum over the workgroups' partial rows [rows][D*wp + 128 + 2n] -> d_lin_w[D,w], d_a[2,64], d_c[2,n].
+// A workgroup sums 16 columns: 16 lane groups take every 16th row (four independent chains each, so the
+// loads overlap), then an LDS reduce.
+__global__ __launch_bounds__(256) void gdn_project_reduce_kernel(const float* __restrict__ part, int rows, int d,
+                                                                 int n, int w, int wp,
+                                                                 float* __restrict__ d_lin_w,
+                                                                 float* __restrict__ d_a,
+                                                                 float* __restrict__ d_c) {
+  __shared__ float red[16][17];
+  const int len = d * wp + 128 + 2 * n;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (t < len) {
+    int r = g;
+    for (; r + 48 < rows; r += 64) {
+      s0 += part[(size_t)r * len + t];
+      s1 += part[(size_t)(r + 16) * len + t];
+      s2 += part[(size_t)(r + 32) * len + t];
+      s3 += part[(size_t)(r + 48) * len + t];
+    }
+    for (; r < rows; r += 16) s0 += part[(size_t)r * len + t];
   }
-  for (int t = tid; t < 128; t += nth) atomicAdd(&d_a[t], da[t]);
-  for (int t = tid; t < 2 * n; t += nth) atomicAdd(&d_c[t], dc[t]);
+  red[g][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0 || t >= len) return;
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += red[q][c];
+  if (t < d * wp) {
+    const int cc = t / d, r = t - cc * d;     // partial rows hold d_lin_w column-major (c*D + d)
+    if (cc < w) d_lin_w[(size_t)r * w + cc] = s;
+  } else if (t < d * wp + 128) {
+    d_a[t - d * wp] = s;
+  } else {
+    d_c[t - d * wp - 128] = s;
+  }
 }
 
 // Chain rule through the folded constants a = lin^T att (node_terms) and c = emb . att_em:
@@ -400,6 +497,8 @@ int occupancy_grid(K kern, int threads, int lds, int batch) {
   return min(batch, gdn_cu_count() * nb);
 }
 
+#define GDN_PBWD_MAX_ROWS 1024   // partial rows (= workgroups) of gdn_project_bwd
+
 }  // namespace
 
 extern "C" int gdn_rev_pitch(int n) { return (n + 15) & ~15; }
@@ -429,18 +528,24 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
   int off = 0;
   pl.off_tile = off; off += (n + 1) * d;
   pl.off_sj = off; off += npad;
+  pl.off_si = off; off += npad;
   pl.off_al = off; off += n * pl.pitch;
   pl.off_dpi = off; off += n * pl.pitch;
   pl.off_dbias = off; off += d;
+  pl.off_nbr = off; off += n * pl.pitch / 2;   // u16 lists
   pl.lds_bytes = off * 4;
   if (pl.lds_bytes > 160 * 1024) return GDN_ERR_UNSUPPORTED;   // n*d tile + two [n,pitch] tables
   hipStream_t st = (hipStream_t)stream;
-#define GDN_BWD(DD)                                                                                  \
-  case DD: {                                                                                         \
-    const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD>, 256, pl.lds_bytes, batch);              \
-    hipLaunchKernelGGL(gdn_attn_bwd_kernel<DD>, dim3(grid), dim3(256), pl.lds_bytes, st, pl, d_z, xlin, \
-                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias);                \
-  } break;
+#define GDN_BWD_NT(DD, NT)                                                                            \
+  {                                                                                                   \
+    const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD, NT>, NT, pl.lds_bytes, batch);            \
+    hipLaunchKernelGGL((gdn_attn_bwd_kernel<DD, NT>), dim3(grid), dim3(NT), pl.lds_bytes, st, pl, d_z, xlin, \
+                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias);                 \
+  }
+#define GDN_BWD(DD)                                                   \
+  case DD:                                                            \
+    if (wide) GDN_BWD_NT(DD, 512) else GDN_BWD_NT(DD, 256) break;
+  const bool wide = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
   switch (d) {
     GDN_BWD(16)
     GDN_BWD(32)
@@ -448,37 +553,48 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
     GDN_BWD(128)
   }
 #undef GDN_BWD
+#undef GDN_BWD_NT
   return gdn_launch_status();
 }
 
+extern "C" long long gdn_project_bwd_workspace_bytes(int n, int w, int d) {
+  if (n <= 0 || w <= 0 || d <= 0) return 0;
+  const int wp = w <= 8 ? 8 : ((w + 15) & ~15);
+  return (long long)GDN_PBWD_MAX_ROWS * (d * wp + 128 + 2 * n) * (long long)sizeof(float);
+}
+
 extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
-                               int batch, int n, int w, int d, float* d_lin_w, float* d_a, float* d_c,
-                               void* stream) {
-  if (!x || !d_xlin || !d_si || !d_sj || !d_lin_w || !d_a || !d_c || batch <= 0 || n <= 0 || w <= 0)
+                               int batch, int n, int w, int d, float* workspace, float* d_lin_w, float* d_a,
+                               float* d_c, void* stream) {
+  if (!x || !d_xlin || !d_si || !d_sj || !workspace || !d_lin_w || !d_a || !d_c || batch <= 0 || n <= 0 ||
+      w <= 0)
     return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (w > GDN_MAX_W || n > 4096) return GDN_ERR_UNSUPPORTED;
   const int wp = w <= 8 ? 8 : ((w + 15) & ~15);
-  const int lds = (n * wp + d * wp + 128 + 2 * n) * 4;
-  if (lds > 160 * 1024) return GDN_ERR_UNSUPPORTED;
+  const int len = d * wp + 128 + 2 * n;
+  // rows per staged chunk: whole window when it fits ~96 KB (three workgroups per CU at the SWaT shape)
+  int rc = (24576 - 2 * n) / (wp + d + 2);
+  if (rc > n) rc = n;
+  if (rc < 1) return GDN_ERR_UNSUPPORTED;
+  const int lds = (rc * (wp + d + 2) + 2 * n) * 4;
   hipStream_t st = (hipStream_t)stream;
-#define GDN_PB(DD, WW)                                                                              \
-  {                                                                                                 \
-    const int grid = occupancy_grid(gdn_project_bwd_kernel<DD, WW>, 256, lds, batch);               \
-    hipLaunchKernelGGL((gdn_project_bwd_kernel<DD, WW>), dim3(grid), dim3(256), lds, st, batch, n, w, wp, \
-                       x, d_xlin, d_si, d_sj, d_lin_w, d_a, d_c);                                   \
-  }
-#define GDN_PBD(DD)          \
-  case DD:                   \
-    if (wp == 8) GDN_PB(DD, 8) else GDN_PB(DD, 16) break;
+  int grid = 1;
+#define GDN_PB(DD)                                                                                  \
+  case DD: {                                                                                        \
+    grid = min(occupancy_grid(gdn_project_bwd_kernel<DD>, 256, lds, batch), GDN_PBWD_MAX_ROWS);     \
+    hipLaunchKernelGGL((gdn_project_bwd_kernel<DD>), dim3(grid), dim3(256), lds, st, batch, n, w, wp, rc, \
+                       x, d_xlin, d_si, d_sj, workspace);                                           \
+  } break;
   switch (d) {
-    GDN_PBD(16)
-    GDN_PBD(32)
-    GDN_PBD(64)
-    GDN_PBD(128)
+    GDN_PB(16)
+    GDN_PB(32)
+    GDN_PB(64)
+    GDN_PB(128)
   }
-#undef GDN_PBD
 #undef GDN_PB
+  hipLaunchKernelGGL(gdn_project_reduce_kernel, dim3((len + 15) / 16), dim3(256), 0, st, workspace, grid, d, n,
+                     w, wp, d_lin_w, d_a, d_c);
   return gdn_launch_status();
 }
 

@@ -236,11 +236,12 @@ def project_bwd(x, d_xlin, d_si, d_sj, d: int):
     """Gradients of project_fwd: d_lin_w[d,w] (direct term), d_a[2,64], d_c[2,n]."""
     x = _chk(x, name="x")
     b, n, w = x.shape
-    d_lin_w = torch.zeros((d, w), dtype=torch.float32, device=x.device)
-    d_a = torch.zeros((2, 64), dtype=torch.float32, device=x.device)
-    d_c = torch.zeros((2, n), dtype=torch.float32, device=x.device)
+    ws = torch.empty((_lib.load().gdn_project_bwd_workspace_bytes(n, w, d) // 4,), dtype=torch.float32,
+                     device=x.device)
+    flat = torch.empty((d * w + 128 + 2 * n,), dtype=torch.float32, device=x.device)
+    d_lin_w, d_a, d_c = flat[:d * w].view(d, w), flat[d * w:d * w + 128].view(2, 64), flat[d * w + 128:].view(2, n)
     _lib.call("gdn_project_bwd", _ptr(x), _ptr(_chk(d_xlin)), _ptr(_chk(d_si)), _ptr(_chk(d_sj)),
-              b, n, w, d, _ptr(d_lin_w), _ptr(d_a), _ptr(d_c), _stream())
+              b, n, w, d, _ptr(ws), _ptr(d_lin_w), _ptr(d_a), _ptr(d_c), _stream())
     return d_lin_w, d_a, d_c
 
 

@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 6
+#define GDN_ABI_VERSION 7
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -178,10 +178,11 @@ int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n, int k,
                       uint32_t* rent, int32_t* rlen, void* stream);
 
 /* x[BN,w], d_xlin[BN,d], d_si/d_sj[BN] -> d_lin_w[d,w] (direct term), d_a[2,64]
- * (grads of a_i, a_j), d_c[2,n] (grads of c_i, c_j); all accumulated with atomics into
- * caller-zeroed buffers.                                                                */
+ * (grads of a_i, a_j), d_c[2,n] (grads of c_i, c_j); outputs are written, not accumulated.
+ * workspace: gdn_project_bwd_workspace_bytes(n, w, d) bytes (one partial row per workgroup). */
+long long gdn_project_bwd_workspace_bytes(int n, int w, int d);
 int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
-                    int batch, int n, int w, int d,
+                    int batch, int n, int w, int d, float* workspace,
                     float* d_lin_w, float* d_a, float* d_c, void* stream);
 
 /* gdn_terms_bwd: chain rule through gdn_node_terms (a = lin^T att, c = emb . att_em — the
