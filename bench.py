@@ -155,6 +155,26 @@ def fused_roofline(model, x, pred, batch, launches):
             "lds_gather_TBps": round(lds_bytes / (mean_us * 1e-6) / 1e12, 2)}
 
 
+def train_step_line(device, n, w, batch, steps=50):
+    """Extra (not the headline): one optimisation step of the reference's train() (train.py:52-66) at the
+    same shape — HIP forward/backward, HIP train-mode head, fused Adam — replayed from one HIP graph."""
+    from gdn_amd.harness import GraphedTrainStep
+    model = build_model(device)[0].train()
+    step = GraphedTrainStep(model, batch)
+    step.x.copy_(torch.rand_like(step.x))
+    step.y.copy_(torch.rand_like(step.y))
+    for _ in range(3):
+        step.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"batch": batch, "ms_per_step": round(ms, 4), "windows_per_s": round(batch / ms * 1e3, 1),
+            "optimizer": "Adam(fused)", "hip_graph": True, "sensors": n, "window": w}
+
+
 def cpu_baseline(params, budget_s=12.0):
     """The oracle (op-faithful CPU port of the reference forward + numpy scoring) on a bounded
     sample of the same workload."""
@@ -322,6 +342,7 @@ def run():
             ev2.step()
         torch.cuda.synchronize()
         result["value_windows_from_raw_series"] = round(t * args.steps / (time.perf_counter() - t2), 1)
+        result["train_step"] = train_step_line(device, n=x.shape[1], w=x.shape[2], batch=args.batch)
         if not args.skip_cpu:
             result["cpu_baseline"] = cpu_baseline(params)
     if dist is not None:

@@ -347,7 +347,8 @@ class GraphedTrainStep:
     `x` / `y` are the static input buffers: copy each minibatch into them, call `step()`, read
     `loss` (a device scalar) whenever convenient."""
 
-    def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True):
+    def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
+                 split: bool | None = None):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("GraphedTrainStep needs the model on a HIP device")
@@ -362,7 +363,8 @@ class GraphedTrainStep:
                                           fused=True)
         self.use_graph = use_graph
         self._graphs = None
-        self._split = world()[1] > 1
+        # two graphs around the (eager) gradient all-reduce; forced on by `split=True` for rehearsal
+        self._split = world()[1] > 1 if split is None else bool(split)
 
     # the two halves of a step; `loss` is written in place so it survives replays
     def _forward_backward(self):

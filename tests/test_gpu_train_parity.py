@@ -149,9 +149,11 @@ def test_head_train_rejects_single_row(gpu_device):
                            torch.zeros((1, 64), device=gpu_device), torch.zeros((1,), device=gpu_device), None, 1)
 
 
-def test_graphed_train_step_equals_eager_steps(gpu_device):
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_train_step_equals_eager_steps(split, gpu_device):
     """harness.GraphedTrainStep: replaying the captured step trains exactly like launching it eagerly
-    (dropout off so both draw no random numbers), and capturing does not move the parameters."""
+    (dropout off so both draw no random numbers), and capturing does not move the parameters.
+    split=True is the multi-rank form (forward+backward graph, eager all-reduce, optimizer graph)."""
     from gdn_amd.harness import GraphedTrainStep
     from test_gpu_forward_parity import random_params
     b = 64
@@ -163,7 +165,7 @@ def test_graphed_train_step_equals_eager_steps(gpu_device):
         model = random_params(27, 10, 8, 64, seed=3).to(gpu_device)
         model.dp.p = 0.0
         before = [p.detach().clone() for p in model.parameters()]
-        step = GraphedTrainStep(model, b, use_graph=use_graph)
+        step = GraphedTrainStep(model, b, use_graph=use_graph, split=split)
         if use_graph:
             step._capture()
             for p, q in zip(model.parameters(), before):
