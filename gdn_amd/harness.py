@@ -43,26 +43,45 @@ def test(model, dataloader, device=None):
     return avg_loss, [torch.cat(preds).tolist(), torch.cat(gts).tolist(), torch.cat(labs).tolist()]
 
 
-def train(model=None, save_path="", config=None, train_dataloader=None, val_dataloader=None, **_ignored):
+def train(model=None, save_path="", config=None, train_dataloader=None, val_dataloader=None, use_graph=False,
+          **_ignored):
     """Mirror of the reference train() (train.py:27-112): same optimizer, loss, checkpoint and
-    early-stop rule.  Returns the list of per-step losses."""
+    early-stop rule.  Returns the list of per-step losses.
+
+    `use_graph=True` (or config["hip_graph"]) runs every full-size minibatch as one replay of a
+    `GraphedTrainStep` (captured at the first batch's size) and the ragged last batch of an epoch
+    eagerly with the same optimizer; losses stay on the device until the epoch ends (the
+    reference syncs with `.item()` every step)."""
     config = config or {}
+    use_graph = use_graph or bool(config.get("hip_graph", False))
     device = next(model.parameters()).device
-    optimizer = torch.optim.Adam(model.parameters(), lr=0.001, weight_decay=config.get("decay", 0))
+    graphed = None
+    if not use_graph:
+        optimizer = torch.optim.Adam(model.parameters(), lr=0.001, weight_decay=config.get("decay", 0))
     losses, min_loss, stale = [], 1e8, 0
     for _epoch in range(config.get("epoch", 1)):
         model.train()
-        acc = 0.0
+        epoch_losses = []
         for x, labels, _attack, edge_index in train_dataloader:
             x, labels = x.float().to(device), labels.float().to(device)
+            if use_graph and graphed is None:
+                graphed = GraphedTrainStep(model, x.shape[0], lr=0.001, weight_decay=config.get("decay", 0))
+                optimizer = graphed.optimizer
+            if graphed is not None and x.shape[0] == graphed.x.shape[0]:
+                graphed.x.copy_(x)
+                graphed.y.copy_(labels)
+                epoch_losses.append(graphed.step().clone())
+                continue
             optimizer.zero_grad()
             out = model(x, edge_index)
             loss = F.mse_loss(out, labels, reduction="mean")
             loss.backward()
             sync_gradients(model)
             optimizer.step()
-            losses.append(loss.item())
-            acc += losses[-1]
+            epoch_losses.append(loss.detach())
+        step_losses = torch.stack(epoch_losses).tolist() if epoch_losses else []
+        losses.extend(step_losses)
+        acc = float(sum(step_losses))
         if val_dataloader is not None:
             val_loss, _ = test(model, val_dataloader, device)
             if val_loss < min_loss:

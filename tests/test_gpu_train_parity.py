@@ -205,3 +205,43 @@ def test_training_forward_follows_unversioned_parameter_writes(gpu_device):
     model.invalidate_constants()
     model(x, None)
     assert not torch.equal(cached, model.learned_graph)
+
+
+def test_harness_train_reproduces_reference_losses(gpu_device):
+    """harness.train (mirror of train.py:27-112) over the golden 2-batch loader: per-step losses of the
+    reference's own train()."""
+    from gdn_amd import harness
+    data, p = load_golden("train_loop_2step")
+    m = meta(data)
+    model = build_model(p, m, gpu_device)
+    model.dp = FixedMaskDropout([torch.from_numpy(mk).to(gpu_device) for mk in data["masks"]])
+    x, y = torch.from_numpy(data["x"]), torch.from_numpy(data["y"])
+    loader = [(x[s:s + m["b"]], y[s:s + m["b"]], torch.zeros(m["b"]), None) for s in range(0, x.shape[0], m["b"])]
+    losses = harness.train(model, "", {"epoch": 1}, loader, None)
+    np.testing.assert_allclose(losses, data["losses"], atol=2e-5, rtol=0)
+
+
+def test_harness_train_graph_mode_matches_eager(gpu_device, tmp_path):
+    """train(use_graph=True): full minibatches replay the captured step, the ragged last batch runs
+    eagerly with the same optimizer; same losses, same checkpoint as the eager loop."""
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    g = torch.Generator().manual_seed(11)
+    xs, ys = torch.rand((150, 27, 10), generator=g), torch.rand((150, 27), generator=g)
+    loader = [(xs[s:s + 64], ys[s:s + 64], torch.zeros(len(xs[s:s + 64])), None) for s in range(0, 150, 64)]
+    assert [b[0].shape[0] for b in loader] == [64, 64, 22]
+    val = [(xs[:32], ys[:32], torch.zeros(32), None)]
+    out = {}
+    for mode in (False, True):
+        model = random_params(27, 10, 8, 64, seed=4).to(gpu_device)
+        model.dp.p = 0.0
+        path = str(tmp_path / f"best_{mode}.pt")
+        losses = harness.train(model, path, {"epoch": 2}, loader, val, use_graph=mode)
+        out[mode] = (losses, torch.load(path, weights_only=True))
+    assert len(out[True][0]) == 6
+    np.testing.assert_allclose(out[False][0], out[True][0], atol=2e-5, rtol=0)
+    for key, val_e in out[False][1].items():
+        # zero-gradient bias (see the 2-step test) random-walks by +-lr per step; the BatchNorm behind it
+        # tracks the mean of z, which contains that bias
+        tol = 2e-2 if key.endswith("gnn.bias") or key.endswith("0.bn.running_mean") else 1e-4
+        np.testing.assert_allclose(val_e.cpu().numpy(), out[True][1][key].cpu().numpy(), atol=tol, err_msg=key)
