@@ -117,23 +117,37 @@ def sensor_range(n: int, rank: int, world_size: int):
     return shard_range(n, rank, world_size)
 
 
-def sync_gradients(model, group=None) -> None:
-    """Data-parallel gradient averaging: every gradient is packed into ONE flat fp32 bucket
-    (9 729 values = 38 KiB at the SWaT shape), one all-reduce (RCCL over xGMI on GPUs; latency
-    bound at this size), then unpacked.  No-op in a single process."""
-    rank, size = world()
-    if size == 1:
-        return
+def pack_gradients(model, flat: torch.Tensor | None = None) -> torch.Tensor:
+    """All gradients in ONE flat fp32 bucket (9 729 values = 38 KiB at the SWaT shape), written into
+    `flat` when given (a static buffer for HIP-graph capture)."""
+    grads = [p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]
+    if flat is None:
+        return torch.cat(grads)
+    torch.cat(grads, out=flat)
+    return flat
+
+
+def unpack_gradients(model, flat: torch.Tensor, world_size: int) -> None:
+    """Averaged bucket back into the parameters' gradients: one scale, one multi-tensor copy."""
     grads = [p.grad for p in model.parameters() if p.grad is not None]
-    if not grads:
-        return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(size)
-    off = 0
+    if world_size > 1:
+        flat.div_(world_size)
+    views, off = [], 0
     for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
+        views.append(flat[off:off + g.numel()].view_as(g))
         off += g.numel()
+    torch._foreach_copy_(grads, views)
+
+
+def sync_gradients(model, group=None) -> None:
+    """Data-parallel gradient averaging: pack, one all-reduce (RCCL over xGMI on GPUs; latency bound
+    at this size), unpack.  No-op in a single process."""
+    _rank, size = world()
+    if size == 1 or not any(p.grad is not None for p in model.parameters()):
+        return
+    flat = pack_gradients(model)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    unpack_gradients(model, flat, size)
 
 
 def broadcast_parameters(model, src: int = 0) -> None:
@@ -356,12 +370,13 @@ class GraphedTrainStep:
     """One optimisation step of the reference's train() (train.py:52-66: zero_grad, forward, MSE,
     backward, Adam) captured once in a HIP graph and replayed per minibatch.
 
-    At the reference's batch sizes a step is ~60 launches of a few microseconds each, so issuing
+    At the reference's batch sizes a step is ~30 launches of a few microseconds each, so issuing
     them from Python costs more than running them; a replayed graph removes that.  The graph
     covers the per-step rebuild of the sensor graph and the folded attention terms (they depend
-    on the parameters Adam has just changed), the HIP forward/backward of the graph layer, torch's
-    BatchNorm/Linear/dropout kernels and a capturable Adam.  With more than one rank the step is
-    two graphs around the gradient all-reduce (`sync_gradients`), which stays eager.
+    on the parameters Adam has just changed), the HIP forward/backward of the graph layer and of
+    the train-mode head, torch's dropout draw and MSE kernels and a fused, capturable Adam.  With more than one rank the step is
+    two graphs around ONE eager op, the all-reduce of the flat gradient bucket (packing is the
+    tail of the first graph, averaging + unpacking the head of the second).
 
     `x` / `y` are the static input buffers: copy each minibatch into them, call `step()`, read
     `loss` (a device scalar) whenever convenient."""
@@ -384,6 +399,7 @@ class GraphedTrainStep:
         self._graphs = None
         # two graphs around the (eager) gradient all-reduce; forced on by `split=True` for rehearsal
         self._split = world()[1] > 1 if split is None else bool(split)
+        self._flat = None                                # static gradient bucket (split mode)
 
     # the two halves of a step; `loss` is written in place so it survives replays
     def _forward_backward(self):
@@ -392,9 +408,20 @@ class GraphedTrainStep:
         loss = F.mse_loss(out, self.y, reduction="mean")
         loss.backward()
         self.loss.copy_(loss.detach())
+        if self._split:                                  # the bucket is part of the first graph
+            if self._flat is None:
+                self._flat = pack_gradients(self.model)
+            else:
+                pack_gradients(self.model, self._flat)
 
     def _update(self):
+        if self._split:                                  # ... and its unpacking part of the second
+            unpack_gradients(self.model, self._flat, world()[1])
         self.optimizer.step()
+
+    def _all_reduce(self):
+        if world()[1] > 1:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
 
     def _snapshot(self):
         tensors = list(self.model.parameters()) + list(self.model.buffers())
@@ -409,6 +436,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for _ in range(3):
                 self._forward_backward()
+                self._all_reduce()
                 self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -438,13 +466,14 @@ class GraphedTrainStep:
     def step(self):
         if not self.use_graph:
             self._forward_backward()
-            sync_gradients(self.model)
+            if self._split:
+                self._all_reduce()
             self._update()
             return self.loss
         if self._graphs is None:
             self._capture()
         self._graphs[0].replay()
         if self._split:
-            sync_gradients(self.model)
+            self._all_reduce()                           # the only eager op of a multi-rank step
             self._graphs[1].replay()
         return self.loss
