@@ -253,6 +253,44 @@ def train_loop_case():
     print(f"train_loop: losses {losses}")
 
 
+def synthetic_series(n, t, seed):
+    """Three groups of phase-coupled sinusoids + noise (the end-to-end test's training data)."""
+    g = np.random.default_rng(seed)
+    base = np.arange(t)[None, :] * (2 * np.pi / np.array([37.0, 53.0, 71.0]))[:, None]
+    grp = np.repeat(np.arange(3), n // 3)
+    phase = g.uniform(0, 0.3, size=n)[:, None]
+    return (0.5 + 0.4 * np.sin(base[grp] + phase) + 0.01 * g.standard_normal((n, t))).astype(np.float32)
+
+
+def train_curve_case():
+    """Row 15 over a longer horizon: the reference's train() for 6 epochs x 8 batches of 128 windows
+    (48 Adam steps) on a learnable series, dropout off (p=0: no RNG stream to match).  Stores the raw
+    series (windows are rebuilt by the test, datasets/TimeDataset.py:42-58 with stride 1), the initial
+    and final parameters and the loss of every step."""
+    n, w, k, d, bsz, nb, epochs = 12, 8, 4, 32, 128, 8, 6
+    model = build_model(31, n, w, k, d, 1, 256)
+    model.dp.p = 0.0
+    series = synthetic_series(n, bsz * nb + w, seed=1)
+    idx = np.arange(bsz * nb)[:, None] + np.arange(w)[None, :]
+    xs = torch.from_numpy(series[:, idx].transpose(1, 0, 2).copy())
+    ys = torch.from_numpy(series[:, w:].T.copy())
+    ei = fc_edge_index(n)
+    batches = [(xs[i * bsz:(i + 1) * bsz], ys[i * bsz:(i + 1) * bsz], torch.zeros(bsz),
+                ei.unsqueeze(0).repeat(bsz, 1, 1)) for i in range(nb)]
+    out = {"meta_bnwkd": np.array([bsz, n, w, k, d, 1, 256], dtype=np.int64), "series": series,
+           "epochs": np.array(epochs)}
+    out.update(state_arrays(model.state_dict(), "p/"))
+    losses = ref_train.train(model, "/tmp/_gdn_golden_curve.pt", config={"seed": 0, "decay": 0.0, "epoch": epochs},
+                             train_dataloader=batches, val_dataloader=None)
+    out["losses"] = np.array(losses)
+    out.update(state_arrays(model.state_dict(), "p_final/"))
+    model.eval()
+    with torch.no_grad():
+        out["eval_after"] = model(xs[:64], ei.unsqueeze(0).repeat(64, 1, 1)).float().numpy()
+    np.savez_compressed(os.path.join(HERE, "train_curve_48step.npz"), **out)
+    print(f"train_curve: first {losses[0]:.5f} last {losses[-1]:.5f} ({len(losses)} steps)")
+
+
 def score_cases():
     """evaluate.py:6-68 on random [T,N] predictions, even and odd T."""
     for t, n, seed in ((64, 5, 3), (65, 7, 4), (1000, 27, 5)):
@@ -286,6 +324,7 @@ def main():
     run_case("wadi_stress_small_n40_w30_k16_d128", seed=7, b=2, n=40, w=30, k=16, d=128)
     eval_loop_case()
     train_loop_case()
+    train_curve_case()
     score_cases()
 
 
