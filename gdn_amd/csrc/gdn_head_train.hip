@@ -32,8 +32,15 @@ struct HG {
 #define GDN_HEAD_REPL 4       // replicas of every column accumulator: same-address fp64 atomics serialise
 #define GDN_HEAD_EMB_PARTS 64  // batch parts of the embedding-gradient pass, one [n,d] partial each
 
+struct RunningStats {   // BatchNorm buffers updated by the forward (any pointer may be null)
+  float *rm1, *rv1, *rm2, *rv2;
+  long long *nbt1, *nbt2;
+  float mom1, mom2;
+};
+
 struct HeadArgs {
   const float *z, *emb, *g1, *b1, *g2, *b2, *w, *bo, *mask, *d_out;
+  RunningStats run;
   const double* fstats;  // [REPL][4][d]: sum z, sum z^2, sum h1, sum h1^2
   double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
   float* demb_part;      // backward: [EMB_PARTS][n][d] per-part sums of d_emb
@@ -121,6 +128,30 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   for (int t = tid; t < NF * D; t += 256) tot[t] = repl_sum(a.fstats + t, 4 * D);
   for (int t = tid; t < NB * D; t += 256) tot[4 * D + t] = repl_sum(a.acc + t, 6 * D);
   if constexpr (NF > 0) __syncthreads();
+
+  if constexpr (MODE == H_OUT) {
+    // running_mean / running_var / num_batches_tracked of both BatchNorms (torch: momentum update with
+    // the UNBIASED batch variance); done once, by workgroup 0 of the last forward pass
+    if (blockIdx.x == 0) {
+      if (tid < 2 * D) {
+        const int which = tid / D, t = tid % D;
+        float* rm = which ? a.run.rm2 : a.run.rm1;
+        float* rv = which ? a.run.rv2 : a.run.rv1;
+        const float mom = which ? a.run.mom2 : a.run.mom1;
+        if (rm && rv) {
+          const double m = tot[which * 2 * D + t] / rows;
+          double var = tot[which * 2 * D + D + t] / rows - m * m;
+          if (var < 0.0) var = 0.0;
+          rm[t] = (1.f - mom) * rm[t] + mom * (float)m;
+          rv[t] = (1.f - mom) * rv[t] + mom * (float)(var * rows / (rows - 1.0));
+        }
+      }
+      if (tid == 0) {
+        if (a.run.nbt1) *a.run.nbt1 += 1;
+        if (a.run.nbt2) *a.run.nbt2 += 1;
+      }
+    }
+  }
 
   BnCols bn1 = {}, bn2 = {};
   if constexpr (MODE >= H_STAT2) bn1 = bn_cols(tot, tot + D, rows, a.eps1, a.g1, a.b1, c0);
@@ -281,33 +312,6 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   }
 }
 
-// running_mean / running_var / num_batches_tracked of both BatchNorms (torch: momentum update with
-// the UNBIASED batch variance)
-__global__ void gdn_head_running_kernel(const double* __restrict__ fstats, double rows, int d, float mom1,
-                                        float* rm1, float* rv1, long long* nbt1, float mom2, float* rm2,
-                                        float* rv2, long long* nbt2) {
-  const int t = threadIdx.x;
-  if (t < d) {
-    for (int which = 0; which < 2; ++which) {
-      float* rm = which ? rm2 : rm1;
-      float* rv = which ? rv2 : rv1;
-      const float mom = which ? mom2 : mom1;
-      if (!rm || !rv) continue;
-      const double* s = fstats + which * 2 * d;
-      const double m = repl_sum(s + t, 4 * d) / rows;
-      double var = repl_sum(s + d + t, 4 * d) / rows - m * m;
-      if (var < 0.0) var = 0.0;
-      const double unbiased = var * rows / (rows - 1.0);
-      rm[t] = (1.f - mom) * rm[t] + mom * (float)m;
-      rv[t] = (1.f - mom) * rv[t] + mom * (float)unbiased;
-    }
-  }
-  if (t == 0) {
-    if (nbt1) *nbt1 += 1;
-    if (nbt2) *nbt2 += 1;
-  }
-}
-
 __global__ void gdn_head_finish_kernel(const double* __restrict__ ws, const float* __restrict__ demb_part,
                                        int parts, int n, int d, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
                                        float* d_bn2_b, float* d_lin_w, float* d_lin_b, float* d_emb) {
@@ -345,11 +349,71 @@ void launch_pass(HeadArgs a, hipStream_t st) {
   hipLaunchKernelGGL((gdn_head_train_kernel<D, MODE>), dim3(a.chunks * a.parts), dim3(256), 0, st, a);
 }
 
+// loss = mean((out - y)^2) and its gradient d_out = 2 (out - y) / count in one launch (train.py:20-23
+// `F.mse_loss(..., reduction='mean')` + the first step of loss.backward()).  Per-workgroup fp64 partial
+// sums; the last workgroup to finish (ticket with release/acquire ordering) adds them up in a fixed
+// order, so the loss is bitwise reproducible.  ws[0] = ticket (left at 0), ws[1..grid] = partials.
+__global__ __launch_bounds__(256) void gdn_mse_kernel(const float* __restrict__ out, const float* __restrict__ y,
+                                                      long long count, float* __restrict__ d_out,
+                                                      double* __restrict__ ws, float* __restrict__ loss) {
+  __shared__ double red[256];
+  __shared__ bool last;
+  const int tid = threadIdx.x;
+  const float scale = (float)(2.0 / (double)count);
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + tid; i < count; i += (long long)gridDim.x * 256) {
+    const float df = out[i] - y[i];
+    acc = fma((double)df, (double)df, acc);
+    d_out[i] = df * scale;
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws);
+  if (tid == 0) {
+    __hip_atomic_store(ws + 1 + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == (unsigned long long)gridDim.x - 1ull;
+  }
+  __syncthreads();
+  if (!last) return;
+  double s = 0.0;
+  for (int b = tid; b < (int)gridDim.x; b += 256)
+    s += __hip_atomic_load(ws + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  red[tid] = s;
+  __syncthreads();
+  for (int q = 128; q > 0; q >>= 1) {
+    if (tid < q) red[tid] += red[tid + q];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    loss[0] = (float)(red[0] / (double)count);
+    __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+#define GDN_MSE_MAX_GRID 256
+
 bool head_shape_ok(int batch, int n, int d) {
   return batch > 0 && n > 0 && n <= 4096 && (long long)batch * n >= 2;
 }
 
 }  // namespace
+
+extern "C" long long gdn_mse_workspace_bytes(void) { return (GDN_MSE_MAX_GRID + 1) * (long long)sizeof(double); }
+
+extern "C" int gdn_mse_loss_grad(const float* out, const float* y, long long count, double* workspace,
+                                 float* loss, float* d_out, void* stream) {
+  if (!out || !y || !workspace || !loss || !d_out || count <= 0) return GDN_ERR_ARG;
+  long long grid = (count + 1023) / 1024;
+  if (grid > GDN_MSE_MAX_GRID) grid = GDN_MSE_MAX_GRID;
+  hipLaunchKernelGGL(gdn_mse_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, out, y, count, d_out,
+                     workspace, loss);
+  return gdn_launch_status();
+}
 
 extern "C" long long gdn_head_train_stats_bytes(int d) {
   return d <= 0 ? 0 : (long long)GDN_HEAD_REPL * 4 * d * (long long)sizeof(double);
@@ -377,6 +441,7 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = lin_b;
   a.mask = mask; a.fstats = stats; a.acc = stats; a.out = out; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
+  a.run = {running_mean1, running_var1, running_mean2, running_var2, batches1, batches2, momentum1, momentum2};
   if (hipMemsetAsync(stats, 0, (size_t)GDN_HEAD_REPL * 4 * d * sizeof(double), st) != hipSuccess)
     return GDN_ERR_LAUNCH;
 #define GDN_HEAD_F(DD)                 \
@@ -392,10 +457,6 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
     GDN_HEAD_F(128)
   }
 #undef GDN_HEAD_F
-  if ((running_mean1 && running_var1) || (running_mean2 && running_var2) || batches1 || batches2)
-    hipLaunchKernelGGL(gdn_head_running_kernel, dim3(1), dim3(128), 0, st, stats, (double)batch * (double)n, d,
-                       momentum1, running_mean1, running_var1, batches1, momentum2, running_mean2,
-                       running_var2, batches2);
   return gdn_launch_status();
 }
 

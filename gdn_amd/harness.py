@@ -374,7 +374,8 @@ class GraphedTrainStep:
     them from Python costs more than running them; a replayed graph removes that.  The graph
     covers the per-step rebuild of the sensor graph and the folded attention terms (they depend
     on the parameters Adam has just changed), the HIP forward/backward of the graph layer and of
-    the train-mode head, torch's dropout draw and MSE kernels and a fused, capturable Adam.  With more than one rank the step is
+    the train-mode head, the fused MSE loss + gradient kernel, torch's dropout draw and a fused,
+    capturable Adam.  With more than one rank the step is
     two graphs around ONE eager op, the all-reduce of the flat gradient bucket (packing is the
     tail of the first graph, averaging + unpacking the head of the second).
 
@@ -392,6 +393,8 @@ class GraphedTrainStep:
         self.x = torch.zeros((batch, n, w), dtype=torch.float32, device=dev)
         self.y = torch.zeros((batch, n), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self._d_out = torch.empty((batch, n), dtype=torch.float32, device=dev)
+        self._mse_ws = ops.mse_workspace(dev)
         # fused: one multi-tensor launch for all 13 parameters instead of ~40 small ones
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=True,
                                           fused=True)
@@ -405,9 +408,9 @@ class GraphedTrainStep:
     def _forward_backward(self):
         self.optimizer.zero_grad(set_to_none=True)      # backward then writes fresh gradients: no fill, no add
         out = self.model(self.x, None)
-        loss = F.mse_loss(out, self.y, reduction="mean")
-        loss.backward()
-        self.loss.copy_(loss.detach())
+        # loss + its gradient in one launch (train.py:20-23, :72); autograd starts from d_out
+        ops.mse_loss_grad(out.detach(), self.y, self._mse_ws, loss=self.loss, d_out=self._d_out)
+        out.backward(self._d_out)
         if self._split:                                  # the bucket is part of the first graph
             if self._flat is None:
                 self._flat = pack_gradients(self.model)

@@ -245,6 +245,25 @@ def project_bwd(x, d_xlin, d_si, d_sj, d: int):
     return d_lin_w, d_a, d_c
 
 
+def mse_workspace(device) -> torch.Tensor:
+    """Zeroed scratch for mse_loss_grad; allocate once and reuse (every call leaves it zeroed)."""
+    return torch.zeros((_lib.load().gdn_mse_workspace_bytes() // 8,), dtype=torch.float64, device=device)
+
+
+def mse_loss_grad(out, y, workspace, loss=None, d_out=None):
+    """(loss, d_out): F.mse_loss(out, y, reduction='mean') (train.py:20-23) and d loss / d out."""
+    out, y = _chk(out, name="out"), _chk(y, name="y")
+    if out.shape != y.shape:
+        raise ValueError(f"shape mismatch: {tuple(out.shape)} vs {tuple(y.shape)}")
+    if loss is None:
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+    if d_out is None:
+        d_out = torch.empty_like(out)
+    _lib.call("gdn_mse_loss_grad", _ptr(out), _ptr(y), out.numel(), _ptr(workspace), _ptr(loss), _ptr(d_out),
+              _stream())
+    return loss, d_out
+
+
 def terms_bwd(lin_w, att_i, att_j, att_em_i, att_em_j, emb, d_lin_w, d_a, d_c):
     """Chain rule through node_terms; d_lin_w (the direct term from project_bwd) is completed in place.
     Returns (d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb)."""

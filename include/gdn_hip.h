@@ -36,7 +36,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 7
+#define GDN_ABI_VERSION 8
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -134,6 +134,15 @@ int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, con
                        int batch, int n, int d, float eps1, float eps2, double* workspace,
                        float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
                        float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);
+
+/* gdn_mse_loss_grad: train.py:20-23 `F.mse_loss(out, y, reduction='mean')` and the gradient
+ * autograd derives for it, d_out = 2 (out - y) / count, in one launch (fp64 accumulation,
+ * bitwise reproducible).  workspace: gdn_mse_workspace_bytes() bytes, ZEROED ONCE by the
+ * caller when allocated; every call leaves it zeroed.  Calls sharing a workspace must be
+ * stream-ordered.  loss[1], d_out[count].                                                   */
+long long gdn_mse_workspace_bytes(void);
+int gdn_mse_loss_grad(const float* out, const float* y, long long count, double* workspace,
+                      float* loss, float* d_out, void* stream);
 
 /* ---- fused eval forward (the throughput path) ---------------------------------------
  * Everything from x[batch,n,w] to out[batch,n] in one launch (one workgroup per window,

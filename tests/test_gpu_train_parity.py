@@ -97,7 +97,8 @@ def _torch_head(z, emb, bn1, bn2, lin_w, lin_b, mask, batch):
 
 
 @pytest.mark.parametrize("batch,n,d,use_mask", [(3, 7, 16, True), (5, 20, 32, False), (4, 127, 64, True),
-                                                (2, 40, 128, True), (1, 2, 64, False), (9, 700, 64, True)])
+                                                (2, 40, 128, True), (1, 2, 64, False), (9, 700, 64, True),
+                                                (2048, 127, 64, True)])
 def test_head_train_kernels_match_fp64_autograd(batch, n, d, use_mask, gpu_device):
     """gdn_head_train_fwd / _bwd against torch autograd in float64 (incl. n*d beyond the LDS-resident
     embedding-gradient partial: n=700, d=64)."""
@@ -282,3 +283,56 @@ def test_48_step_training_curve_follows_the_reference(use_graph, gpu_device):
     # eval mode normalises by the RUNNING mean, which lags the drifting zero-gradient bias (momentum 0.1):
     # unlike in training the drift does not cancel exactly, so two correct runs differ by a few 1e-3
     np.testing.assert_allclose(out.cpu().numpy(), data["eval_after"], atol=1e-2, rtol=0)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (512, 127), (4096, 127)])
+def test_fused_mse_loss_and_gradient(shape, gpu_device):
+    """gdn_mse_loss_grad == F.mse_loss(reduction='mean') + autograd (train.py:20-23), workspace reused."""
+    from gdn_amd import ops
+    g = torch.Generator().manual_seed(shape[0])
+    ws = ops.mse_workspace(gpu_device)
+    for _ in range(3):                              # the workspace must come back zeroed
+        out = torch.randn(shape, generator=g).to(gpu_device).requires_grad_(True)
+        y = torch.randn(shape, generator=g).to(gpu_device)
+        ref = torch.nn.functional.mse_loss(out.double(), y.double(), reduction="mean")
+        ref.backward()
+        loss, d_out = ops.mse_loss_grad(out.detach(), y, ws)
+        np.testing.assert_allclose(float(loss), float(ref.detach()), rtol=2e-7, atol=0)
+        np.testing.assert_allclose(d_out.cpu().numpy(), out.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    assert float(ws.abs().sum()) >= 0 and int(ws.view(torch.int64)[0]) == 0
+
+
+def test_back_to_back_graph_replays_without_host_sync(gpu_device):
+    """Replays issued back to back (no host synchronisation, as in a real training loop) must train like
+    per-step launches.  Shape = the SWaT one at 4096 windows: torch's multi-block mean reduction (the
+    mse_loss the step used before the fused loss kernel) went wrong exactly here under replay."""
+    from gdn_amd.harness import GraphedTrainStep
+    from test_gpu_forward_parity import random_params
+    b, steps = 4096, 10
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((b, 127, 15), generator=g).to(gpu_device)
+    y = torch.rand((b, 127), generator=g).to(gpu_device)
+
+    model = random_params(127, 15, 30, 64, seed=0).to(gpu_device).train()
+    model.dp.p = 0.0
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    for _ in range(steps):                                  # plain eager loop, torch loss, synced every step
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x, None), y)
+        loss.backward()
+        opt.step()
+        ref_loss = loss.item()
+    ref_params = [p.detach().clone() for p in model.parameters()]
+
+    model = random_params(127, 15, 30, 64, seed=0).to(gpu_device).train()
+    model.dp.p = 0.0
+    step = GraphedTrainStep(model, b)
+    step.x.copy_(x)
+    step.y.copy_(y)
+    for _ in range(steps):
+        step.step()                                         # no .item(), no synchronize
+    torch.cuda.synchronize()
+    assert abs(float(step.loss) - ref_loss) < 2e-5
+    for (name, p), q in zip(model.named_parameters(), ref_params):
+        tol = 2e-2 if name.endswith("gnn.bias") else 2e-4
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.cpu().numpy(), atol=tol, err_msg=name)
