@@ -178,3 +178,24 @@ def test_blocked_key_select_equals_whole_series_quantiles(t, n, ranks, gpu_devic
         got = ops.score_select(recv.reshape(-1), ranks, b - a, pitch, t)
         assert torch.equal(got, want[a:b])
         assert torch.equal(recv.view(torch.int64), keep.view(torch.int64))   # the input is not modified
+
+
+def test_evaluator_replays_back_to_back_at_bench_size(gpu_device):
+    """What bench.py's timed region does — graph replays with no host sync in between, 4 side streams,
+    8 minibatches per launch, T=32768 — must end with the same predictions and anomaly scores as the
+    un-graphed, per-launch path."""
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    model = random_params(127, 15, 30, 64, seed=2).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(8)
+    t = 32768
+    x = torch.rand((t, 127, 15), generator=g).to(gpu_device)
+    y = torch.rand((t, 127), generator=g).to(gpu_device)
+    ref = harness.SeriesEvaluator(model, x, y, batch=512, coalesce=1, use_graph=False, streams=1)
+    want = ref.step().clone()
+    ev = harness.SeriesEvaluator(model, x, y, batch=512, coalesce=8, use_graph=True, streams=4)
+    for _ in range(6):
+        ev.step()                                          # no synchronisation between replays
+    torch.cuda.synchronize()
+    assert torch.equal(ev.pred, ref.pred)
+    assert torch.equal(ev.anomaly, want)
