@@ -234,6 +234,8 @@ def run():
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="side streams the forward launches rotate over")
+    ap.add_argument("--exchange-chunk", type=int, default=16384,
+                    help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="1 rank, but run the N>1 step (RCCL process group, all-to-all scoring exchange)")
@@ -266,11 +268,10 @@ def run():
     if world == 1 and not args.rehearse_dist:
         step = ev.step
     else:
-        total = t * world
-
-        def step():
-            ev.forward_only()
-            return harness.distributed_anomaly(ev.pred, y, total, rehearse=args.rehearse_dist)
+        # N>1: windows shard by rank with no collective in the forward; the scoring exchange (all-to-all of
+        # the radix keys by sensor) is issued per chunk of ticks and overlaps the forward of the following chunks
+        sev = harness.ShardedEvaluator(model, x, y, t * world, chunk=args.exchange_chunk)
+        step = sev.step
 
     for _ in range(args.warmup):
         step()
@@ -305,7 +306,9 @@ def run():
                        "batch": batch, "batches_per_launch": max(1, args.coalesce),
                        "windows_per_launch": launch_batch, "windows_per_rank_per_step": t, "storage": "fp32",
                        "hip_graph": not args.no_graph, "forward_streams": args.streams,
-                       "parallelism": f"windows sharded over {world} rank(s); scoring all-to-all by sensor"
+                       "parallelism": f"windows sharded over {world} rank(s), no forward collective; scoring keys "
+                                      f"all-to-all by sensor in chunks of {args.exchange_chunk} ticks (async, overlapping "
+                                      "the forward) + one all-gather"
                        if world > 1 else "single GPU"},
         }
     if rank == 0:

@@ -166,8 +166,8 @@ class HipScoreBackend:
     exercise the exchange logic on CPU (gloo)."""
 
     @staticmethod
-    def keys(pred_tn, gt_tn, pitch):
-        return ops.score_keys(pred_tn, gt_tn, pitch)
+    def keys(pred_tn, gt_tn, pitch, out=None):
+        return ops.score_keys(pred_tn, gt_tn, pitch, out=out)
 
     @staticmethod
     def select(keys_flat, blocks, n, pitch, total):
@@ -248,6 +248,101 @@ def distributed_anomaly(pred_local, gt_local, total_ticks: int, backend=HipScore
     if t_local == 0:
         return torch.empty((0,), dtype=torch.float64, device=dev)
     return backend.smooth_max(pred_local, gt_local, med_iqr, first_tick, halo_p, halo_g)
+
+
+class ShardedEvaluator:
+    """The multi-rank eval step with its one real exchange hidden behind the forward.
+
+    Same arithmetic as `SeriesEvaluator.forward_only()` + `distributed_anomaly()`, reorganised for one
+    process per GPU over xGMI:
+      * the local shard runs in chunks of `chunk` ticks; as soon as a chunk's predictions exist its
+        radix keys (already transposed to [sensor, tick], rows grouped by owning rank) leave in an
+        ASYNC `all_to_all_single`, so the transfers (N*T*8 bytes per rank in total) overlap the
+        forward of the following chunks; only the last chunk's transfer is exposed;
+      * the receive side is one [chunk, rank, my sensors, pitch] buffer = `chunks*ranks` row blocks of
+        the blocked radix select — no packing or unpacking on either side;
+      * every buffer, and the index tables that pick the median/IQR rows and the 3-tick halo out of the
+        ONE all-gather that follows, are built once: a step issues no allocation-heavy torch code.
+    `forward(start, stop)` must fill `self.pred[start:stop]`; the default runs the fused HIP forward."""
+
+    def __init__(self, model, x_local, y_local: torch.Tensor, total_ticks: int, chunk: int = 4096,
+                 backend=HipScoreBackend, forward=None, group=None):
+        self.rank, self.size = world()
+        self.group, self.backend, self.model = group, backend, model
+        self.x, self.y, self.total = x_local, y_local, total_ticks
+        self.t, self.n = y_local.shape
+        dev = y_local.device
+        size, n = self.size, self.n
+        self.bounds = [shard_range(total_ticks, r, size) for r in range(size)]
+        if self.bounds[self.rank][1] - self.bounds[self.rank][0] != self.t:
+            raise ValueError("y_local does not have this rank's share of the ticks (harness.shard_range)")
+        self.sens = [sensor_range(n, r, size) for r in range(size)]
+        s0, s1 = self.sens[self.rank]
+        self.n_mine = s1 - s0
+        longest = max(e - s for s, e in self.bounds)
+        # every rank must agree on chunk count and pitch: both follow from the LONGEST shard
+        self.pitch = max(KEY_SLICE, (min(chunk, longest) + KEY_SLICE - 1) // KEY_SLICE * KEY_SLICE)
+        self.nchunks = max(1, (longest + self.pitch - 1) // self.pitch)
+        self.pred = torch.empty((self.t, n), dtype=torch.float32, device=dev)
+        filler = torch.full((self.nchunks, n, self.pitch), -1, dtype=torch.int64, device=dev)
+        self.send = filler.view(torch.float64)          # chunks this rank has no ticks for stay all filler
+        self.recv = torch.empty((self.nchunks, size, self.n_mine, self.pitch), dtype=torch.float64, device=dev)
+        self.in_sizes = [(b - a) * self.pitch for a, b in self.sens]
+        self.out_sizes = [self.n_mine * self.pitch] * size
+        # published row: [my median/IQR rows, padded to the largest share | last 3 (pred, y) rows, right aligned]
+        self.cap = max(b - a for a, b in self.sens)
+        self.row = self.cap * 2 + 6 * n
+        self.pub = torch.zeros((self.row,), dtype=torch.float64, device=dev)
+        self.take = min(3, self.t)
+        if self.take:
+            self.pub[self.cap * 2:].view(2, 3, n)[1, 3 - self.take:] = y_local[self.t - self.take:].double()
+        self.gathered = torch.empty((size * self.row,), dtype=torch.float64, device=dev)
+        mi_idx = [r * self.row + (s - a) * 2 + h for r, (a, b) in enumerate(self.sens) for s in range(a, b)
+                  for h in (0, 1)]
+        self.mi_idx = torch.tensor(mi_idx, dtype=torch.int64, device=dev)
+        # the 3 ticks before my first one, newest last; a shard shorter than 3 ticks makes them span ranks
+        self.first_tick = self.bounds[self.rank][0]
+        src = []                                        # (rank, row in its right-aligned 3-row tail)
+        for r in range(self.rank - 1, -1, -1):
+            have = min(3, self.bounds[r][1] - self.bounds[r][0])
+            src.extend((r, 2 - j) for j in range(have))
+            if len(src) >= 3:
+                break
+        src = (src[:3] + [(0, 0)] * 3)[:3][::-1]        # ticks before tick 0 are never read: any valid index
+        halo_idx = [[[r * self.row + self.cap * 2 + which * 3 * n + j * n + c for c in range(n)] for r, j in src]
+                    for which in (0, 1)]
+        self.halo_idx = torch.tensor(halo_idx, dtype=torch.int64, device=dev)
+        self.forward = forward if forward is not None else self._hip_forward
+
+    def _hip_forward(self, start, stop):
+        self.model.forward_into(self.x[start:stop], self.pred[start:stop])
+
+    def step(self):
+        works = []
+        for c in range(self.nchunks):
+            a, b = min(self.t, c * self.pitch), min(self.t, (c + 1) * self.pitch)
+            if b > a:
+                self.forward(a, b)
+                self.backend.keys(self.pred[a:b], self.y[a:b], self.pitch, out=self.send[c])
+            works.append(dist.all_to_all_single(self.recv[c].reshape(-1), self.send[c].reshape(-1),
+                                                self.out_sizes, self.in_sizes, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if self.n_mine:
+            mi = self.backend.select(self.recv.reshape(-1), self.nchunks * self.size, self.n_mine, self.pitch,
+                                     self.total)
+            self.pub[: self.n_mine * 2] = mi.reshape(-1)
+        if self.take:
+            self.pub[self.cap * 2:].view(2, 3, self.n)[0, 3 - self.take:] = self.pred[self.t - self.take:]
+        dist.all_gather_into_tensor(self.gathered, self.pub, group=self.group)
+        med_iqr = self.gathered[self.mi_idx].view(self.n, 2)
+        halo_p = halo_g = None
+        if self.first_tick > 0:
+            halo = self.gathered[self.halo_idx].to(self.pred.dtype)
+            halo_p, halo_g = halo[0], halo[1]
+        if self.t == 0:
+            return torch.empty((0,), dtype=torch.float64, device=self.pred.device)
+        return self.backend.smooth_max(self.pred, self.y, med_iqr, self.first_tick, halo_p, halo_g)
 
 
 # --------------------------------------------------------------------------- resident-series evaluator

@@ -283,11 +283,13 @@ def score_workspace(t: int, n: int, device) -> torch.Tensor:
     return torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=device)
 
 
-def score_keys(pred, gt, pitch: int) -> torch.Tensor:
+def score_keys(pred, gt, pitch: int, out: torch.Tensor | None = None) -> torch.Tensor:
     """keys[n, pitch] float64 = |pred-gt| transposed (radix keys); slots t..pitch-1 = filler."""
     pred, gt = _chk(pred, name="pred"), _chk(gt, name="gt")
     t, n = pred.shape
-    keys = torch.empty((n, pitch), dtype=torch.float64, device=pred.device)
+    keys = out if out is not None else torch.empty((n, pitch), dtype=torch.float64, device=pred.device)
+    if keys.shape != (n, pitch) or keys.dtype != torch.float64 or not keys.is_contiguous():
+        raise ValueError("keys buffer must be a contiguous float64 [n, pitch] tensor")
     _lib.call("gdn_score_keys", _ptr(pred), _ptr(gt), t, n, pitch, _ptr(keys), _stream())
     return keys
 

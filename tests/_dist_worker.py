@@ -20,10 +20,13 @@ class OracleScoreBackend:
     """CPU stand-in for HipScoreBackend: same three entry points, arithmetic from the oracle / numpy."""
 
     @staticmethod
-    def keys(pred_tn, gt_tn, pitch):
+    def keys(pred_tn, gt_tn, pitch, out=None):
         t, n = pred_tn.shape
         k = torch.full((n, pitch), float("nan"), dtype=torch.float64)          # filler slots
         k[:, :t] = (pred_tn.double() - gt_tn.double()).abs().t()
+        if out is not None:
+            out.copy_(k)
+            return out
         return k
 
     @staticmethod
@@ -67,6 +70,25 @@ def main():
                                             backend=OracleScoreBackend)
         want = score_oracle.anomaly_score(score_oracle.full_err_scores(pred.numpy(), gt.numpy()))
         np.testing.assert_allclose(local.numpy(), want[s:e], rtol=1e-12, atol=1e-13)
+
+    # the chunk-overlapped evaluator: several chunks, a partly filled one, ranks with fewer chunks than others
+    for total, n, chunk in ((9000, 5, 2048), (4099, 7, 2048), (40, 3, 4096), (5, 2, 4096), (2, 4, 2048)):
+        g = torch.Generator().manual_seed(total + 1)
+        pred = torch.rand((total, n), generator=g)
+        gt = pred + 0.1 * torch.randn((total, n), generator=g)
+        s, e = harness.shard_range(total, rank, size)
+        box = {}
+
+        def fwd(a, b, box=box, s=s):                       # "forward" = copy the precomputed predictions
+            box["ev"].pred[a:b] = pred[s + a:s + b]
+
+        ev = harness.ShardedEvaluator(None, None, gt[s:e].contiguous(), total, chunk=chunk,
+                                      backend=OracleScoreBackend, forward=fwd)
+        box["ev"] = ev
+        want = score_oracle.anomaly_score(score_oracle.full_err_scores(pred.numpy(), gt.numpy()))
+        for _ in range(2):                                 # buffers are reused across steps
+            local = ev.step()
+            np.testing.assert_allclose(local.numpy(), want[s:e], rtol=1e-12, atol=1e-13)
 
     # flat-bucket gradient averaging
     torch.manual_seed(0)

@@ -199,3 +199,36 @@ def test_evaluator_replays_back_to_back_at_bench_size(gpu_device):
     torch.cuda.synchronize()
     assert torch.equal(ev.pred, ref.pred)
     assert torch.equal(ev.anomaly, want)
+
+
+def test_sharded_evaluator_one_rank_rccl_equals_series_evaluator(gpu_device):
+    """harness.ShardedEvaluator (the N>1 eval step: per-chunk async all-to-all of the radix keys, blocked
+    select over chunks*ranks row blocks, one all-gather) run with a 1-rank RCCL group on this GPU: same
+    predictions and anomaly scores as the single-GPU evaluator, also across repeated steps.  The
+    multi-rank exchange logic itself is covered with gloo in tests/test_cpu_distributed.py."""
+    import socket
+    import torch.distributed as dist
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=gpu_device)
+    try:
+        model = random_params(127, 15, 30, 64, seed=3).to(gpu_device).eval()
+        g = torch.Generator().manual_seed(12)
+        t = 9000                                           # 3 chunks of 4096 slots, the last partly filled
+        x = torch.rand((t, 127, 15), generator=g).to(gpu_device)
+        y = torch.rand((t, 127), generator=g).to(gpu_device)
+        ref = harness.SeriesEvaluator(model, x, y, batch=512, use_graph=False, streams=1)
+        want = ref.step().clone()
+        sev = harness.ShardedEvaluator(model, x, y, t, chunk=4096)
+        assert sev.nchunks == 3 and sev.pitch == 4096
+        for _ in range(3):
+            got = sev.step()
+        torch.cuda.synchronize()
+        assert torch.equal(sev.pred, ref.pred)
+        assert torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()
