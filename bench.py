@@ -4,7 +4,7 @@
 The series is resident, so by default 8 consecutive 512-window minibatches go out as one launch
 (`--coalesce 1` launches per minibatch; `value_per_batch_launches` reports that variant too).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -51,19 +51,33 @@ def build_model(device):
     return model.to(device).eval(), params
 
 
-def event_time_launches(launch, count):
+def event_time_launches(launch, count, settle_ms=60.0):
     """Average device time per launch: `count` back-to-back launches on the launch stream between two
     HIP events (the queue never drains, so this is kernel time + the ~1.5 us dependent-launch gap; an
-    event pair per launch adds ~5 us of its own and was dropped).  Repeated 3x, (mean, best) in us."""
-    runs = []
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    event pair per launch adds ~5 us of its own and was dropped).  Three such runs, recorded in-stream
+    with no host synchronisation in between; (mean, best) in us.
+
+    The runs are preceded, in the same stream and without a gap, by ~`settle_ms` of the same launches:
+    this GPU needs ~50 ms of sustained load after an idle period to reach its steady clocks
+    (tools/probe_ramp.py: the same graph replay takes 0.84 ms right after a synchronize and 0.67 ms
+    sixty replays later), and a kernel's roofline fraction is a statement about steady state."""
+    probe0, probe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    probe0.record()
+    for i in range(4):
+        launch(i)
+    probe1.record()
+    torch.cuda.synchronize()
+    per_launch_ms = max(probe0.elapsed_time(probe1) / 4, 1e-3)
+    for i in range(int(settle_ms / per_launch_ms) + 1):
+        launch(i)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    marks[0].record()
+    for r in range(3):
         for i in range(count):
             launch(i)
-        e1.record()
-        torch.cuda.synchronize()
-        runs.append(1e3 * e0.elapsed_time(e1) / count)
+        marks[r + 1].record()
+    torch.cuda.synchronize()
+    runs = [1e3 * marks[r].elapsed_time(marks[r + 1]) / count for r in range(3)]
     return sum(runs) / len(runs), min(runs)
 
 
@@ -226,8 +240,8 @@ def main():
 def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=512, help="logical minibatch (BASELINE configs[2])")
     ap.add_argument("--coalesce", type=int, default=8,
                     help="consecutive minibatches of the resident series sent as one launch (1 = per-batch launches)")
@@ -312,15 +326,13 @@ def run():
                        if world > 1 else "single GPU"},
         }
     if rank == 0:
-        pred = ev.pred
-        sweep = []
-        for b in sorted({batch, launch_batch, t}):
-            sweep.append(k8_roofline(model, x, b, launches=max(12, min(64, 65536 // b))))
+        launches_for = lambda b: max(12, min(64, 65536 // b))
+        sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sorted({batch, launch_batch, t})]
         # the launch size the timed region uses
         result["roofline"] = next(r for r in sweep if r["batch"] == launch_batch)
         result["roofline_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
                                      "launch_us": r["launch_us"]} for r in sweep]
-        result["roofline_fused"] = fused_roofline(model, x, pred, launch_batch, launches=max(12, min(64, 65536 // launch_batch)))
+        result["roofline_fused"] = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch))
         if args.coalesce > 1 and world == 1:      # transparency: the same step with one launch per logical minibatch
             ev1 = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams)
             for _ in range(args.warmup):
