@@ -247,7 +247,7 @@ def run():
                     help="consecutive minibatches of the resident series sent as one launch (1 = per-batch launches)")
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="side streams the forward launches rotate over")
+    ap.add_argument("--streams", type=int, default=2, help="side streams the forward launches rotate over")
     ap.add_argument("--exchange-chunk", type=int, default=16384,
                     help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
     ap.add_argument("--skip-cpu", action="store_true")
