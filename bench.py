@@ -250,6 +250,8 @@ def run():
     ap.add_argument("--streams", type=int, default=2, help="side streams the forward launches rotate over")
     ap.add_argument("--exchange-chunk", type=int, default=16384,
                     help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
+    ap.add_argument("--sweep-max", type=int, default=262144,
+                    help="largest launch of the K8 roofline sweep (0 = stop at --ticks)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="1 rank, but run the N>1 step (RCCL process group, all-to-all scoring exchange)")
@@ -328,6 +330,11 @@ def run():
     if rank == 0:
         launches_for = lambda b: max(12, min(64, 65536 // b))
         sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sorted({batch, launch_batch, t})]
+        if world == 1 and args.sweep_max > t:       # the fraction at the largest per-GPU launch
+            xbig = torch.rand((args.sweep_max, N_SENSORS, WINDOW), device=device)     # 2 GB; xlin + z: 17 GB
+            sweep.append(k8_roofline(model, xbig, args.sweep_max, launches=12))
+            del xbig
+            torch.cuda.empty_cache()
         # the launch size the timed region uses
         result["roofline"] = next(r for r in sweep if r["batch"] == launch_batch)
         result["roofline_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],

@@ -187,3 +187,26 @@ def test_windows_read_from_the_raw_series_equal_materialised_windows(n, w, k, d,
     assert torch.equal(got, want)
     part = model.forward_series(series, 37, 101)
     assert torch.equal(part, want[37:138])
+
+
+def test_262144_window_launch_equals_small_launches(gpu_device):
+    """SURVEY §8d's largest launch (xlin alone is 8.5 GB: every row offset needs 64-bit addressing): the
+    staged kernels and the fused forward on 262144 windows give, bit for bit, what 512-window launches of
+    the same rows give — including the last rows of the buffers."""
+    from gdn_amd import ops
+    b = 262144
+    model = random_params(127, 15, 30, 64, seed=0).to(gpu_device).eval()
+    gnn = model.gnn_layers[0].gnn
+    c = model._constants()
+    x = torch.rand((b, 127, 15), device=gpu_device)
+    xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
+    z, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, b, want_alpha=False)
+    with torch.no_grad():
+        fused = model(x, None)
+    for s in (0, 51200, b // 2 + 37, b - 512):
+        xs = x[s:s + 512].contiguous()
+        with torch.no_grad():
+            assert torch.equal(model(xs, None), fused[s:s + 512]), s
+        xl2, si2, sj2 = ops.project_fwd(xs, gnn.lin.weight, c.terms)
+        z2, _ = ops.attn_aggregate_fwd(xl2, si2, sj2, c.graph, gnn.bias, 512, want_alpha=False)
+        assert torch.equal(xl2, xlin[s * 127:(s + 512) * 127]) and torch.equal(z2, z[s * 127:(s + 512) * 127]), s
