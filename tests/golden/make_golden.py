@@ -308,6 +308,39 @@ def score_cases():
         print(f"score T={t} N={n}: scores {np.asarray(scores).shape}")
 
 
+def performance_cases():
+    """evaluate.py:99-158 + util/data.py:28-51 (threshold sweep, F1, precision, recall, AUC)
+    by the reference's own functions (scipy rankdata, sklearn metrics) on scored series with attack
+    bursts; ties in the scores are forced in the second case (ordinal ranks break them by position)."""
+    ref_data = importlib.import_module("util.data")
+    for name, t, n, seed, quant in (("perf_T1000_N27", 1000, 27, 8, 0), ("perf_T777_N5_ties", 777, 5, 9, 2)):
+        g = torch.Generator().manual_seed(seed)
+        pred = torch.rand((t, n), generator=g)
+        gt = (pred + 0.1 * torch.randn((t, n), generator=g)).float()
+        labels = np.zeros(t)
+        for a, b in ((t // 5, t // 5 + 25), (t // 2, t // 2 + 40), (t - 60, t - 45)):
+            gt[a:b, : max(1, n // 4)] += 0.8
+            labels[a:b] = 1
+        if quant:
+            pred, gt = torch.round(pred, decimals=quant), torch.round(gt, decimals=quant)
+        res = [pred.tolist(), gt.tolist(), np.tile(labels[:, None], (1, n)).tolist()]
+        scores, normals = ref_eval.get_full_err_scores(res, res)
+        scores = np.asarray(scores)
+        out = {"pred": pred.numpy(), "gt": gt.numpy(), "labels": labels.copy(), "scores": scores}
+        for topk in (1, 3):
+            total = np.sum(np.take_along_axis(scores, np.argpartition(
+                scores, range(scores.shape[0] - topk - 1, scores.shape[0]), axis=0)[-topk:], axis=0), axis=0)
+            fmeas, ths = ref_data.eval_scores(total.tolist(), labels.tolist(), 400, return_thresold=True)
+            out[f"fmeas_top{topk}"] = np.array(fmeas)
+            out[f"thresholds_top{topk}"] = np.array(ths)
+            out[f"best_top{topk}"] = np.array(ref_eval.get_best_performance_data(scores, labels.copy().tolist(), topk=topk))
+            # "normal" scores for the validation rule: the first fifth of the series (no attack there)
+            out[f"val_top{topk}"] = np.array(ref_eval.get_val_performance_data(
+                scores, scores[:, : t // 6], labels.copy().tolist(), topk=topk))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(f"{name}: best {out['best_top1']} val {out['val_top1']}")
+
+
 def main():
     torch.set_num_threads(4)
     xs, ys, raw = msl_slice(5, 8)
@@ -326,6 +359,7 @@ def main():
     train_loop_case()
     train_curve_case()
     score_cases()
+    performance_cases()
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ def _windows(series):
 
 def test_train_eval_score_finds_injected_fault(gpu_device):
     from gdn_amd import GDN, harness
-    from gdn_amd.evaluate import get_full_err_scores, get_top1_anomaly
+    from gdn_amd.evaluate import get_best_performance_data, get_full_err_scores, get_top1_anomaly
     torch.manual_seed(0)
     model = GDN([torch.zeros((2, 1), dtype=torch.long)], N, dim=D, input_dim=W, topk=K).to(gpu_device)
     xtr, ytr = _windows(_series(2048 + W, seed=1))
@@ -56,6 +56,10 @@ def test_train_eval_score_finds_injected_fault(gpu_device):
     # neighbours' predictions are corrupted through the attention, as in the reference)
     assert np.median(anomaly[lab]) > 3.0 * np.median(anomaly[~lab])
     assert (anomaly[lab] > np.quantile(anomaly[~lab], 0.99)).mean() > 0.5
+
+    # the reference's report (main.py:139-147 -> evaluate.py:129-158): best-F1 threshold sweep, AUC
+    f1, pre, rec, auc, thr = get_best_performance_data(scores, labels.numpy(), topk=1)
+    assert f1 > 0.6 and auc > 0.9 and 0 < pre <= 1 and 0 < rec <= 1 and thr > np.median(anomaly)
 
     # the resident-series evaluator gives the same anomaly score as the loop above
     ev = harness.SeriesEvaluator(model, xte.to(gpu_device), yte.to(gpu_device), batch=256, use_graph=True)

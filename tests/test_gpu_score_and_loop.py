@@ -232,3 +232,41 @@ def test_sharded_evaluator_one_rank_rccl_equals_series_evaluator(gpu_device):
         assert torch.equal(got, want)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["perf_T1000_N27", "perf_T777_N5_ties"])
+def test_threshold_sweep_matches_reference_evaluate(case, gpu_device):
+    """SURVEY §8f-4 on the device: gdn_amd.evaluate.get_best_performance_data / get_val_performance_data /
+    eval_scores against what the reference's own functions (scipy rankdata, sklearn metrics) returned."""
+    import os
+    from gdn_amd import evaluate
+    data = np.load(os.path.join(os.path.dirname(__file__), "golden", case + ".npz"))
+    scores, labels = data["scores"], data["labels"]
+    dev_scores, _ = evaluate.get_full_err_scores([data["pred"], data["gt"], None], device=gpu_device)
+    np.testing.assert_allclose(dev_scores, scores, rtol=1e-12, atol=1e-13)
+    for topk in (1, 3):
+        total = np.sort(scores, axis=0)[scores.shape[0] - topk:].sum(axis=0)
+        fmeas, ths = evaluate.eval_scores(total.tolist(), labels.tolist(), 400, return_thresold=True, device=gpu_device)
+        np.testing.assert_allclose(fmeas, data[f"fmeas_top{topk}"], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(ths, data[f"thresholds_top{topk}"], rtol=1e-15, atol=0)
+        best = evaluate.get_best_performance_data(scores, labels.tolist(), topk=topk, device=gpu_device)
+        np.testing.assert_allclose(best, data[f"best_top{topk}"], rtol=1e-12, atol=0)
+        val = evaluate.get_val_performance_data(scores, scores[:, : scores.shape[1] // 6], labels.tolist(), topk=topk,
+                                                device=gpu_device)
+        np.testing.assert_allclose(val, data[f"val_top{topk}"], rtol=1e-12, atol=0)
+
+
+def test_threshold_sweep_full_size_against_oracle(gpu_device):
+    """The sweep at T=32768 (the bench's series) against the oracle's numpy restatement, ties included."""
+    from gdn_amd import evaluate
+    from oracle import score_oracle
+    g = np.random.default_rng(3)
+    t, n = 32768, 127
+    scores = np.round(g.gamma(2.0, 0.6, size=(n, t)), 3)                      # rounded: many tied scores
+    labels = np.zeros(t)
+    for a in range(2000, t, 4096):
+        labels[a:a + 150] = 1
+        scores[:7, a:a + 150] += 6.0
+    for topk in (1, 2):
+        got = evaluate.get_best_performance_data(scores, labels, topk=topk, device=gpu_device)
+        np.testing.assert_allclose(got, score_oracle.best_performance(scores, labels, topk), rtol=1e-12, atol=0)

@@ -94,3 +94,23 @@ def test_eval_loop_fixture_consistent_with_oracle():
     np.testing.assert_allclose(sum(losses) / len(losses), float(data["avg_loss"]), atol=1e-6)
     s = score_oracle.full_err_scores(data["pred"].astype(np.float64), data["gt"].astype(np.float64))
     np.testing.assert_allclose(s, data["scores"], atol=1e-12, rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["perf_T1000_N27", "perf_T777_N5_ties"])
+def test_threshold_sweep_oracle_matches_reference_evaluate(case):
+    """the oracle's sweep / F1 / precision / recall / AUC against the reference's own
+    evaluate.get_best_performance_data / get_val_performance_data / util.data.eval_scores."""
+    import os
+    from oracle import score_oracle
+    data = np.load(os.path.join(os.path.dirname(__file__), "golden", case + ".npz"))
+    scores, labels = data["scores"], data["labels"]
+    np.testing.assert_allclose(score_oracle.full_err_scores(data["pred"], data["gt"]), scores, rtol=1e-12, atol=1e-13)
+    for topk in (1, 3):
+        fmeas, ths = score_oracle.eval_scores(score_oracle.topk_total(scores, topk), labels)
+        np.testing.assert_allclose(fmeas, data[f"fmeas_top{topk}"], rtol=1e-13, atol=0)
+        np.testing.assert_array_equal(ths, data[f"thresholds_top{topk}"])
+        np.testing.assert_allclose(score_oracle.best_performance(scores, labels, topk), data[f"best_top{topk}"],
+                                   rtol=1e-12, atol=0)
+        normal = scores[:, : scores.shape[1] // 6]
+        np.testing.assert_allclose(score_oracle.val_performance(scores, normal, labels, topk), data[f"val_top{topk}"],
+                                   rtol=1e-12, atol=0)
