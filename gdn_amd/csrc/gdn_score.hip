@@ -318,6 +318,217 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, 
   if (tid == 0) write_result(prefix, sa, s, med_iqr);
 }
 
+// Whole select in ONE workgroup per sensor, for sensors whose slots fit the register file of a
+// 1024-thread workgroup (32 keys per thread = 32768 slots: the single-GPU series of the bench).  No global
+// histograms, no tickets, no inter-block hand-offs, one launch instead of five:
+//   digits 0-1 over the keys in registers (read from HBM once; 32-bit math on the high word);
+//   keys matching some rank's 16-bit prefix (a few percent) are compacted into LDS, digit 2 runs on those;
+//   keys matching a 24-bit prefix (a handful) are compacted again and every rank is finished by
+//   COUNTING: a thread per candidate counts the smaller / equal candidates of its bucket.
+// Inputs that defeat the compaction (e.g. a constant sensor: every key matches) fall back to digit
+// passes over LDS or registers, still inside this launch.
+constexpr int ONE_NT = 1024;
+constexpr int ONE_FK = 32;
+constexpr int ONE_CAP = 8192;   // 16-bit-prefix survivors kept in LDS (64 KB)
+constexpr int ONE_CAP2 = 1024;  // 24-bit-prefix survivors finished by counting
+
+__global__ __launch_bounds__(ONE_NT) void select_onewg_kernel(const KeyLayout kl, const SelectArgs sa,
+                                                              double* __restrict__ med_iqr) {
+  __shared__ unsigned int hist[NQ][256];
+  __shared__ unsigned long long prefix[NQ];
+  __shared__ unsigned long long stage[ONE_CAP];
+  __shared__ unsigned long long stage2[ONE_CAP2];
+  __shared__ int rem[NQ];
+  __shared__ int rep[NQ];
+  __shared__ unsigned int n_stage, n_stage2;
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned int slots = (unsigned int)kl.blocks * (unsigned int)kl.pitch;
+  unsigned long long key[ONE_FK];
+#pragma unroll
+  for (int u = 0; u < ONE_FK; ++u) {
+    const unsigned int i = tid + u * ONE_NT;
+    unsigned long long k = FILLER;
+    if (i < slots) {
+      const unsigned int blk = i / (unsigned int)kl.pitch, off = i - blk * (unsigned int)kl.pitch;
+      k = kl.keys[((size_t)blk * kl.n + s) * kl.pitch + off];
+    }
+    key[u] = k;
+  }
+  if (tid < NQ) {
+    prefix[tid] = 0ull;
+    rem[tid] = sa.rank[tid];
+  }
+  if (tid == 0) {
+    n_stage = 0u;
+    n_stage2 = 0u;
+  }
+  __syncthreads();
+#ifdef GDN_SELECT_TIMING
+  long long tick[12];
+  int nt = 0;
+  tick[nt++] = wall_clock64();
+#endif
+  bool in_lds = false;       // digits >= 2 read the compacted survivors
+  bool done = false;
+  unsigned int n_keep = 0u;
+  for (int pass = 0; pass < 8 && !done; ++pass) {
+    const int shift = 56 - 8 * pass;
+    if (tid < NQ) {
+      int r = tid;
+      for (int q = tid - 1; q >= 0; --q)
+        if (prefix[q] == prefix[tid]) r = q;
+      rep[tid] = r;
+    }
+    for (int i = tid; i < NQ * 256; i += ONE_NT) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    unsigned long long pf[NQ];
+    bool active[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      pf[q] = prefix[q];
+      active[q] = rep[q] == q;
+    }
+    if (!in_lds && pass < 3) {
+      // digits 0-2 live in the HIGH word of the key: 32-bit shifts and compares
+      const unsigned int sh = 24u - 8u * (unsigned int)pass;
+      unsigned int pfh[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) pfh[q] = (unsigned int)(pf[q] >> 32);
+#pragma unroll
+      for (int u = 0; u < ONE_FK; ++u) {
+        const unsigned int hi = (unsigned int)(key[u] >> 32);
+        const bool real = (int)hi >= 0;               // keys are non-negative doubles; the filler is all ones
+        const unsigned int digit = (hi >> sh) & 255u;
+        const unsigned int d0 = __builtin_amdgcn_readfirstlane(digit);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (!active[q]) continue;   // uniform
+          const bool match = real && (pass == 0 ? true : ((hi ^ pfh[q]) >> (sh + 8u)) == 0u);
+          if (__all(match && digit == d0)) {          // a whole wave in one bin (the exponent bytes): one add
+            if (lane == 0) atomicAdd(&hist[q][d0], 64u);
+          } else if (match) {
+            atomicAdd(&hist[q][digit], 1u);
+          }
+        }
+      }
+    } else if (!in_lds) {
+#pragma unroll
+      for (int u = 0; u < ONE_FK; ++u) {
+        const unsigned long long k = key[u];
+        const bool real = k != FILLER;
+        const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (!active[q]) continue;
+          if (real && ((k ^ pf[q]) >> (shift + 8)) == 0ull) atomicAdd(&hist[q][digit], 1u);
+        }
+      }
+    } else {
+      for (unsigned int i = tid; i < n_keep; i += ONE_NT) {
+        const unsigned long long k = stage[i];
+        const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (!active[q]) continue;
+          if (((k ^ pf[q]) >> (shift + 8)) == 0ull) atomicAdd(&hist[q][digit], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    for (int q = wv; q < NQ; q += ONE_NT / 64)
+      locate_bin(hist[rep[q]], rem[q], pf[q], shift, lane, &prefix[q], &rem[q]);
+    __syncthreads();
+    if (pass == 1) {
+      // compact the keys that still match some rank's 16-bit prefix; stay in registers if they do not fit
+      unsigned int p16[NQ];                            // distinct 16-bit prefixes as scalars; 0x10000 = unused
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        p16[q] = __builtin_amdgcn_readfirstlane((unsigned int)(prefix[q] >> 48));
+#pragma unroll
+        for (int r = 0; r < q; ++r)
+          if (p16[r] == p16[q]) p16[q] = 0x10000u;
+      }
+      unsigned int keep = 0u;                          // bit u: my key u survives
+#pragma unroll
+      for (int u = 0; u < ONE_FK; ++u) {
+        const unsigned int h16 = (unsigned int)(key[u] >> 48);   // the filler (0xffff) never equals a prefix
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) any |= h16 == p16[q];
+        keep |= any ? (1u << u) : 0u;
+      }
+      // one LDS atomic per WAVE: lanes scan their survivor counts, the last lane reserves the range
+      const int mine = __popc(keep);
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      unsigned int base = 0u;
+      if (lane == 63) base = atomicAdd(&n_stage, (unsigned int)incl);
+      base = __shfl(base, 63);
+      unsigned int pos = base + (unsigned int)(incl - mine);
+#pragma unroll
+      for (int u = 0; u < ONE_FK; ++u) {
+        if ((keep >> u) & 1u) {
+          if (pos < (unsigned int)ONE_CAP) stage[pos] = key[u];
+          ++pos;
+        }
+      }
+      __syncthreads();
+      n_keep = n_stage;
+      in_lds = n_keep <= (unsigned int)ONE_CAP;
+    }
+    if (pass == 2 && in_lds) {
+      // second compaction (24-bit prefixes), then finish every rank by counting inside its bucket
+      for (unsigned int i = tid; i < n_keep; i += ONE_NT) {
+        const unsigned long long k = stage[i];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) any |= ((k ^ prefix[q]) >> 40) == 0ull;
+        if (any) {
+          const unsigned int at = atomicAdd(&n_stage2, 1u);
+          if (at < (unsigned int)ONE_CAP2) stage2[at] = k;
+        }
+      }
+      __syncthreads();
+      const unsigned int n2 = n_stage2;
+      if (n2 <= (unsigned int)ONE_CAP2) {
+        if ((unsigned int)tid < n2) {
+          const unsigned long long k = stage2[tid];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const unsigned long long pq = prefix[q];
+            if (((k ^ pq) >> 40) != 0ull) continue;
+            int less = 0, equal = 0;
+            for (unsigned int j = 0; j < n2; ++j) {
+              const unsigned long long o = stage2[j];
+              if (((o ^ pq) >> 40) != 0ull) continue;
+              less += o < k ? 1 : 0;
+              equal += o == k ? 1 : 0;
+            }
+            const int want = rem[q];                    // 0-based position inside the bucket
+            if (less <= want && want < less + equal) prefix[q] = k;   // equal keys write the same value
+          }
+        }
+        __syncthreads();
+        done = true;
+      }
+    }
+#ifdef GDN_SELECT_TIMING
+    tick[nt++] = wall_clock64();
+#endif
+  }
+#ifdef GDN_SELECT_TIMING
+  if (tid == 0 && s == 1)
+    printf("onewg ticks(10ns): load+p0 %lld p1+compact %lld p2+finish %lld (passes run %d) survivors %u / %u\n",
+           tick[1] - tick[0], tick[2] - tick[1], tick[3] - tick[2], nt - 1, n_keep, n_stage2);
+#endif
+  if (tid == 0) write_result(prefix, sa, s, med_iqr);
+}
+
 // Normalise, smooth, max.  One wave owns a run of consecutive ticks; lane l owns sensors l, l+64, ...
 // and slides a 4-deep window of normalised errors down the run, so each (tick, sensor) value — and
 // its float64 division — is computed once.  smoothed = mean of the value at the tick and its 3
@@ -407,6 +618,16 @@ SelectArgs make_select_args(long long t) {
   return sa;
 }
 
+// diagnostic knob: GDN_SELECT_MULTI=1 forces the multi-launch path at every size (tests, comparisons)
+bool force_multi_block() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GDN_SELECT_MULTI");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 int run_select(const double* keys, int blocks, int n, int pitch, long long total, double* workspace,
                double* med_iqr, hipStream_t st) {
   const long long slots = (long long)blocks * pitch;
@@ -417,6 +638,11 @@ int run_select(const double* keys, int blocks, int n, int pitch, long long total
   SelState* state = reinterpret_cast<SelState*>(kl.bufb + (size_t)slots * n);
   const SelectArgs sa = make_select_args(total);
   const int slices = (int)((slots + SLICE - 1) / SLICE);
+  if (slices > 1 && slots <= (long long)ONE_NT * ONE_FK && !force_multi_block()) {
+    // the whole sensor fits one workgroup's registers: one launch, no global state
+    hipLaunchKernelGGL(select_onewg_kernel, dim3(n), dim3(ONE_NT), 0, st, kl, sa, med_iqr);
+    return gdn_launch_status();
+  }
   hipLaunchKernelGGL(select_init_kernel, dim3(n), dim3(256), 0, st, state, sa);
   if (slices == 1) {   // tiny input: everything in the finisher, straight from the input
     hipLaunchKernelGGL(select_finish_kernel<false>, dim3(n), dim3(256), 0, st, kl, state, 0, sa, med_iqr);
