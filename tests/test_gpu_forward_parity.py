@@ -210,3 +210,21 @@ def test_262144_window_launch_equals_small_launches(gpu_device):
         xl2, si2, sj2 = ops.project_fwd(xs, gnn.lin.weight, c.terms)
         z2, _ = ops.attn_aggregate_fwd(xl2, si2, sj2, c.graph, gnn.bias, 512, want_alpha=False)
         assert torch.equal(xl2, xlin[s * 127:(s + 512) * 127]) and torch.equal(z2, z[s * 127:(s + 512) * 127]), s
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_eval_forward_against_float64_oracle(case, gpu_device):
+    """Accuracy rather than parity: the eval forward (fused, or staged + MLP for out_layer_num > 1) against
+    the oracle run in float64 on the same parameters, inputs and sensor graph: 2e-6 (+1e-5 relative),
+    i.e. 50x inside north_star's 1e-4 bar."""
+    data, p = load_golden(case)
+    m = meta(data)
+    model = build_model(p, m, gpu_device)
+    model.injected_graph = torch.from_numpy(data["learned_graph"]).to(gpu_device)
+    x = torch.from_numpy(data["x"])
+    with torch.no_grad():
+        out = model(x.to(gpu_device), None)
+    f64 = torch.float64
+    p64 = {k: (v.to(f64) if v.is_floating_point() else v) for k, v in p.items()}
+    ref = gdn_oracle.forward(p64, x.to(f64), m["k"], m["out_layer_num"], graph=torch.from_numpy(data["learned_graph"]))
+    np.testing.assert_allclose(out.cpu().numpy().astype(np.float64), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
