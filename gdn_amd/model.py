@@ -13,10 +13,12 @@ forward on CPU tensors raises.
   eval, out_layer_num == 1 : one fused launch  x[B,N,W] -> out[B,N]       (ops.forward_fused)
   eval, otherwise          : project -> attention/aggregate -> head kernels, OutLayer MLP
                              through torch (plain library GEMMs)
-  train                    : project + attention/aggregate forward AND backward are HIP kernels
-                             (autograd.Function below); BatchNorm batch statistics, dropout
-                             and the output MLP use torch ops so `loss.backward()` reaches
-                             every parameter exactly as in the reference.
+  train, out_layer_num == 1: project + attention/aggregate AND the BatchNorm/ReLU/embedding/
+                             dropout/Linear head run as HIP kernels forward and backward (the
+                             two autograd.Functions below); torch draws the dropout mask
+  train, otherwise         : the graph layer as above, BatchNorm statistics, dropout and the
+                             output MLP through torch ops
+                             (`loss.backward()` reaches every parameter exactly as in the reference)
 """
 from __future__ import annotations
 
@@ -325,7 +327,7 @@ class GDN(nn.Module):
                 out = self.out_layer(h2.view(batch, node_num, -1))
             return out.view(-1, node_num)
 
-        # ---- training: HIP forward/backward for the graph layer, torch for BN statistics etc.
+        # ---- training: HIP forward/backward for the graph layer and (out_layer_num == 1) the head
         z, alpha = _GraphAttentionFn.apply(x, gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i,
                                            gnn.att_em_j, emb, gnn.bias, c.graph, batch, c.terms)
         layer._set_dense((alpha, c.graph, batch))

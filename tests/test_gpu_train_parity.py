@@ -1,5 +1,6 @@
 """GPU suite: one training step (train.py:68-72 usage) — HIP forward + HIP backward of the graph
-layer, torch for BN statistics / dropout / MLP — against the gradients the reference produced."""
+layer and of the train-mode head (torch only for the dropout draw and the out_layer_num > 1 MLP) — against
+the gradients the reference produced, the reference's loss curves, and the float64 oracle."""
 import numpy as np
 import pytest
 import torch
