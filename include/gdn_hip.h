@@ -19,8 +19,15 @@
  *     window-major order (row = b*n + sensor), the layout of models/GDN.py:130;
  *   - re-entrant across distinct streams.
  *
- * Supported shapes: d in {16, 32, 64, 128}; 1 <= w <= 64; 1 <= k <= n <= 4096 with
- * k+1 <= 1024; anything else returns GDN_ERR_UNSUPPORTED (never a silent fallback).
+ * Supported shapes: d in {16, 32, 64, 128}; 1 <= w <= 64; 1 <= k <= n with k+1 <= 1024,
+ * and the window's working set must fit the 160 KB of LDS of one CU:
+ *   forward (staged and fused): the xlin tile (n+1)*dc*4 bytes, dc = d (d = 128: 64, two
+ *     column slices) — n up to ~600 at d = 64/128, ~1000 at d = 32, ~2000 at d = 16;
+ *   backward (gdn_attn_aggregate_bwd): that tile at full d PLUS two [n, pitch] fp32 tables
+ *     and the lists — n up to ~250 at d = 64 with k = 30 (127-sensor WADI, 51-sensor SWaT
+ *     and the 25-55-sensor MSL/SMAP/PSM sets fit; the 512-sensor stress shape trains
+ *     only at d <= 16);
+ * anything else returns GDN_ERR_UNSUPPORTED (never a silent fallback).
  */
 #ifndef GDN_HIP_H
 #define GDN_HIP_H
