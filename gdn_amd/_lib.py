@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -25,10 +25,10 @@ SIGNATURES = {
     "gdn_project_fwd": [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p],
     "gdn_attn_aggregate_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_head_fwd": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],
-    "gdn_head_train_fwd": [_p] * 9 + [_c_int] * 3 + [_c_float] * 4 + [_p] * 9,
+    "gdn_head_train_fwd": [_p] * 10 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 9,
     "gdn_head_train_workspace_bytes": [_c_int, _c_int],
     "gdn_head_train_stats_bytes": [_c_int],
-    "gdn_head_train_bwd": [_p] * 10 + [_c_int] * 3 + [_c_float] * 2 + [_p] * 10,
+    "gdn_head_train_bwd": [_p] * 10 + [_c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 10,
     "gdn_mse_workspace_bytes": [],
     "gdn_mse_loss_grad": [_p, _p, ctypes.c_longlong, _p, _p, _p, _p],
     "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],

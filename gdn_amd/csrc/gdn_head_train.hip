@@ -40,6 +40,8 @@ struct RunningStats {   // BatchNorm buffers updated by the forward (any pointer
 
 struct HeadArgs {
   const float *z, *emb, *g1, *b1, *g2, *b2, *w, *bo, *mask, *d_out;
+  const uint8_t* keep;   // alternative to `mask`: 1 = kept, 0 = dropped, value = keep * keep_scale
+  float keep_scale;
   RunningStats run;
   const double* fstats;  // [REPL][4][d]: sum z, sum z^2, sum h1, sum h1^2
   double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
@@ -188,7 +190,13 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
         const size_t row = (size_t)b * a.n + n;
         ld4(a.z + row * D + c0, zq[u]);
         mq[u][0] = mq[u][1] = mq[u][2] = mq[u][3] = 1.f;
-        if (MODE >= H_OUT && a.mask) ld4(a.mask + row * D + c0, mq[u]);
+        if (MODE >= H_OUT && a.mask) {
+          ld4(a.mask + row * D + c0, mq[u]);
+        } else if (MODE >= H_OUT && a.keep) {           // one byte per element: a quarter of the mask traffic
+          const uchar4 kb = *reinterpret_cast<const uchar4*>(a.keep + row * D + c0);
+          mq[u][0] = kb.x * a.keep_scale; mq[u][1] = kb.y * a.keep_scale;
+          mq[u][2] = kb.z * a.keep_scale; mq[u][3] = kb.w * a.keep_scale;
+        }
         goq[u] = MODE >= H_BWD2 ? a.d_out[row] : 0.f;
       }
 #pragma unroll
@@ -427,7 +435,8 @@ extern "C" long long gdn_head_train_workspace_bytes(int n, int d) {
 
 extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
                                   const float* bn2_w, const float* bn2_b, const float* lin_w,
-                                  const float* lin_b, const float* mask, int batch, int n, int d, float eps1,
+                                  const float* lin_b, const float* mask, const uint8_t* keep, float keep_scale, int batch, int n,
+                                  int d, float eps1,
                                   float eps2, float momentum1, float momentum2, float* running_mean1,
                                   float* running_var1, long long* batches1, float* running_mean2,
                                   float* running_var2, long long* batches2, double* stats, float* out,
@@ -439,7 +448,8 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
   hipStream_t st = (hipStream_t)stream;
   HeadArgs a = {};
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = lin_b;
-  a.mask = mask; a.fstats = stats; a.acc = stats; a.out = out; a.batch = batch; a.n = n;
+  a.mask = mask; a.keep = mask ? nullptr : keep; a.keep_scale = keep_scale;
+  a.fstats = stats; a.acc = stats; a.out = out; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
   a.run = {running_mean1, running_var1, running_mean2, running_var2, batches1, batches2, momentum1, momentum2};
   if (hipMemsetAsync(stats, 0, (size_t)GDN_HEAD_REPL * 4 * d * sizeof(double), st) != hipSuccess)
@@ -462,7 +472,8 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
 
 extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, const float* bn1_w,
                                   const float* bn1_b, const float* bn2_w, const float* bn2_b,
-                                  const float* lin_w, const float* mask, const double* stats, int batch,
+                                  const float* lin_w, const float* mask, const uint8_t* keep, float keep_scale,
+                                  const double* stats, int batch,
                                   int n, int d, float eps1, float eps2, double* workspace, float* d_z,
                                   float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
                                   float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream) {
@@ -474,7 +485,8 @@ extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const floa
   hipStream_t st = (hipStream_t)stream;
   HeadArgs a = {};
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = nullptr;
-  a.mask = mask; a.d_out = d_out; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
+  a.mask = mask; a.keep = mask ? nullptr : keep; a.keep_scale = keep_scale;
+  a.d_out = d_out; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
   const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
   a.demb_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sums_bytes);

@@ -99,10 +99,10 @@ class _HeadTrainFn(torch.autograd.Function):
     as three streaming HIP passes forward and three backward; batch statistics in fp64."""
 
     @staticmethod
-    def forward(ctx, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, lin_b, mask, bn1, bn2, batch):
-        out, stats = ops.head_train_fwd(z, emb, bn1, bn2, lin_w, lin_b, mask, batch)
+    def forward(ctx, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, lin_b, mask, mask_scale, bn1, bn2, batch):
+        out, stats = ops.head_train_fwd(z, emb, bn1, bn2, lin_w, lin_b, mask, batch, mask_scale)
         ctx.save_for_backward(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, stats)
-        ctx.mask, ctx.eps, ctx.batch = mask, (float(bn1.eps), float(bn2.eps)), batch
+        ctx.mask, ctx.mask_scale, ctx.eps, ctx.batch = mask, mask_scale, (float(bn1.eps), float(bn2.eps)), batch
         ctx.shapes = (lin_w.shape, lin_b.shape)
         return out
 
@@ -111,9 +111,9 @@ class _HeadTrainFn(torch.autograd.Function):
         z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, stats = ctx.saved_tensors
         d_z, d_emb, g1w, g1b, g2w, g2b, glw, glb = ops.head_train_bwd(
             d_out.contiguous(), z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, ctx.mask, stats,
-            ctx.eps[0], ctx.eps[1], ctx.batch)
+            ctx.eps[0], ctx.eps[1], ctx.batch, ctx.mask_scale)
         return (d_z, d_emb, g1w, g1b, g2w, g2b, glw.view(ctx.shapes[0]), glb.view(ctx.shapes[1]),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class GNNLayer(nn.Module):
@@ -333,9 +333,9 @@ class GDN(nn.Module):
         layer._set_dense((alpha, c.graph, batch))
         if self.out_layer_num == 1 and self._hip_train_head_ok():
             lin = self.out_layer.mlp[0]
-            mask = self._dropout_mask(batch, node_num, emb.shape[1], x.device)
+            mask, mask_scale = self._dropout_mask(batch, node_num, emb.shape[1], x.device)
             return _HeadTrainFn.apply(z, emb, layer.bn.weight, layer.bn.bias, self.bn_outlayer_in.weight,
-                                      self.bn_outlayer_in.bias, lin.weight, lin.bias, mask, layer.bn,
+                                      self.bn_outlayer_in.bias, lin.weight, lin.bias, mask, mask_scale, layer.bn,
                                       self.bn_outlayer_in, batch)
         # out_layer_num > 1 (MLP head): torch for BN statistics, dropout and the library GEMMs
         h = layer.relu(layer.bn(z))                                         # GDN.py:77-79
@@ -350,16 +350,25 @@ class GDN(nn.Module):
         return all(b.affine and (not b.track_running_stats or b.momentum is not None) for b in bns)
 
     def _dropout_mask(self, batch, node_num, d, device):
-        """[B,N,d] multiplier of models/GDN.py:182 (0 or 1/(1-p)), drawn by `self.dp` itself so torch's
-        generator (and a replaced `dp` module) keep their meaning; None when dropout is off."""
+        """(mask, scale) of models/GDN.py:182, or (None, 1).  A plain `nn.Dropout` is drawn as ONE byte
+        per element from torch's generator (`bernoulli_`; multiplier = keep * 1/(1-p)) — a quarter of the
+        bytes of an fp32 mask, which four head passes re-read; any other `dp` module (tests install
+        fixed masks) is asked for its fp32 multipliers by feeding it ones."""
         dp = self.dp
-        if not dp.training or (isinstance(dp, nn.Dropout) and dp.p == 0):
-            return None
+        if type(dp) is nn.Dropout:
+            if not dp.training or dp.p == 0:
+                return None, 1.0
+            if dp.p >= 1:
+                return torch.zeros((batch * node_num, d), dtype=torch.uint8, device=device), 0.0
+            keep = torch.empty((batch * node_num, d), dtype=torch.uint8, device=device).bernoulli_(1.0 - dp.p)
+            return keep, 1.0 / (1.0 - dp.p)
+        if not dp.training:
+            return None, 1.0
         ones = getattr(self, "_ones", None)
         if ones is None or ones.shape != (batch, node_num, d) or ones.device != device or getattr(dp, "inplace", False):
             ones = torch.ones((batch, node_num, d), dtype=torch.float32, device=device)
             self._ones = None if getattr(dp, "inplace", False) else ones
-        return dp(ones).reshape(batch * node_num, d)
+        return dp(ones).reshape(batch * node_num, d), 1.0
 
     def forward_into(self, data, out):
         """Eval fast path writing into a caller-owned [B, N] slice (no allocation, HIP-graph

@@ -141,30 +141,39 @@ def _bn_running(bn):
     return float(bn.momentum), bn.running_mean, bn.running_var, bn.num_batches_tracked
 
 
-def head_train_fwd(z, emb, bn1, bn2, lin_w, lin_b, mask, batch: int):
+def _mask_args(mask, numel: int, scale: float):
+    """(fp32 multiplier pointer, byte keep-mask pointer, scale) for the train-mode head."""
+    if mask is None:
+        return None, None, 1.0
+    if mask.numel() != numel:
+        raise ValueError("dropout mask must have batch*n*d elements")
+    if mask.dtype == torch.uint8:
+        return None, _ptr(_chk(mask, dtype=torch.uint8, name="dropout keep mask")), float(scale)
+    return _ptr(_chk(mask, name="dropout mask")), None, 1.0
+
+
+def head_train_fwd(z, emb, bn1, bn2, lin_w, lin_b, mask, batch: int, mask_scale: float = 1.0):
     """Train-mode head (models/GDN.py:77-79,175-184, out_layer_num == 1): returns (out[B,n], stats).
-    Updates the running statistics of the two BatchNorm modules `bn1`, `bn2` in place."""
+    `mask`: fp32 multipliers [B*n, d] (0 or 1/(1-p)), or a uint8 keep mask (1/0) with `mask_scale` =
+    1/(1-p), or None.  Updates the running statistics of the BatchNorm modules `bn1`, `bn2` in place."""
     z = _chk(z, name="z")
     bn, d = z.shape
     n = bn // batch
     out = torch.empty((batch, n), dtype=torch.float32, device=z.device)
     stats = torch.empty((_lib.load().gdn_head_train_stats_bytes(d) // 8,), dtype=torch.float64, device=z.device)
-    if mask is not None:
-        mask = _chk(mask, name="dropout mask")
-        if mask.numel() != z.numel():
-            raise ValueError("dropout mask must have batch*n*d elements")
+    mptr, kptr, kscale = _mask_args(mask, z.numel(), mask_scale)
     m1, rm1, rv1, nb1 = _bn_running(bn1)
     m2, rm2, rv2, nb2 = _bn_running(bn2)
     _lib.call("gdn_head_train_fwd", _ptr(z), _ptr(_chk(emb.detach())), _ptr(_chk(bn1.weight.detach())),
               _ptr(_chk(bn1.bias.detach())), _ptr(_chk(bn2.weight.detach())), _ptr(_chk(bn2.bias.detach())),
-              _ptr(_chk(lin_w.detach().reshape(-1))), _ptr(_chk(lin_b.detach().reshape(-1))), _ptr(mask),
+              _ptr(_chk(lin_w.detach().reshape(-1))), _ptr(_chk(lin_b.detach().reshape(-1))), mptr, kptr, kscale,
               batch, n, d, float(bn1.eps), float(bn2.eps), m1, m2, _ptr(rm1), _ptr(rv1), _ptr(nb1),
               _ptr(rm2), _ptr(rv2), _ptr(nb2), _ptr(stats), _ptr(out), _stream())
     return out, stats
 
 
 def head_train_bwd(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, mask, stats, eps1: float, eps2: float,
-                   batch: int):
+                   batch: int, mask_scale: float = 1.0):
     """Gradients of head_train_fwd: (d_z, d_emb, d_bn1_w, d_bn1_b, d_bn2_w, d_bn2_b, d_lin_w, d_lin_b)."""
     d_out = _chk(d_out, name="d_out")
     bn, d = z.shape
@@ -176,8 +185,9 @@ def head_train_bwd(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, mask, stats
     small = torch.empty((5 * d + 1,), dtype=torch.float32, device=dev)
     g1w, g1b, g2w, g2b, glw = (small[i * d:(i + 1) * d] for i in range(5))
     glb = small[5 * d:]
+    mptr, kptr, kscale = _mask_args(mask, z.numel(), mask_scale)
     _lib.call("gdn_head_train_bwd", _ptr(d_out), _ptr(z), _ptr(_chk(emb)), _ptr(_chk(bn1_w)), _ptr(_chk(bn1_b)),
-              _ptr(_chk(bn2_w)), _ptr(_chk(bn2_b)), _ptr(_chk(lin_w.reshape(-1))), _ptr(mask), _ptr(stats),
+              _ptr(_chk(bn2_w)), _ptr(_chk(bn2_b)), _ptr(_chk(lin_w.reshape(-1))), mptr, kptr, kscale, _ptr(stats),
               batch, n, d, eps1, eps2, _ptr(ws), _ptr(d_z), _ptr(d_emb), _ptr(g1w), _ptr(g1b), _ptr(g2w),
               _ptr(g2b), _ptr(glw), _ptr(glb), _stream())
     return d_z, d_emb, g1w, g1b, g2w, g2b, glw, glb

@@ -43,7 +43,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 8
+#define GDN_ABI_VERSION 9
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -116,7 +116,9 @@ int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
  * normalise by the statistics of this batch (models/GDN.py:77-79 GNNLayer.bn, :178-180
  * bn_outlayer_in — biased variance over all batch*n rows) and update running_mean /
  * running_var (momentum, unbiased variance) / num_batches_tracked; dropout (:182) is applied
- * as the caller's mask[BN,d] (0 or 1/(1-p); NULL = no dropout); OutLayer Linear(d->1).
+ * as the caller's mask: either mask[BN,d] fp32 multipliers (0 or 1/(1-p)) or keep[BN,d] bytes
+ * (1 kept / 0 dropped, multiplier = keep * keep_scale: a quarter of the traffic); both NULL =
+ * no dropout; OutLayer Linear(d->1).
  *   stats (out)  gdn_head_train_stats_bytes(d) bytes: replicated fp64 column sums of z, z^2,
  *                h1, h1^2 — opaque, kept for the backward.
  *   running_* / batches*     may be NULL (track_running_stats off).
@@ -124,7 +126,8 @@ int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
 long long gdn_head_train_stats_bytes(int d);
 int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
                        const float* bn2_w, const float* bn2_b, const float* lin_w,
-                       const float* lin_b, const float* mask, int batch, int n, int d,
+                       const float* lin_b, const float* mask, const uint8_t* keep,
+                       float keep_scale, int batch, int n, int d,
                        float eps1, float eps2, float momentum1, float momentum2,
                        float* running_mean1, float* running_var1, long long* batches1,
                        float* running_mean2, float* running_var2, long long* batches2,
@@ -137,7 +140,8 @@ int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, con
 long long gdn_head_train_workspace_bytes(int n, int d);
 int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, const float* bn1_w,
                        const float* bn1_b, const float* bn2_w, const float* bn2_b,
-                       const float* lin_w, const float* mask, const double* stats,
+                       const float* lin_w, const float* mask, const uint8_t* keep,
+                       float keep_scale, const double* stats,
                        int batch, int n, int d, float eps1, float eps2, double* workspace,
                        float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
                        float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);

@@ -99,7 +99,8 @@ def _torch_head(z, emb, bn1, bn2, lin_w, lin_b, mask, batch):
 
 @pytest.mark.parametrize("batch,n,d,use_mask", [(3, 7, 16, True), (5, 20, 32, False), (4, 127, 64, True),
                                                 (2, 40, 128, True), (1, 2, 64, False), (9, 700, 64, True),
-                                                (2048, 127, 64, True)])
+                                                (2048, 127, 64, True), (6, 127, 64, "u8"), (3, 33, 128, "u8"),
+                                                (5, 9, 16, "u8")])
 def test_head_train_kernels_match_fp64_autograd(batch, n, d, use_mask, gpu_device):
     """gdn_head_train_fwd / _bwd against torch autograd in float64 (incl. n*d beyond the LDS-resident
     embedding-gradient partial: n=700, d=64)."""
@@ -123,12 +124,14 @@ def test_head_train_kernels_match_fp64_autograd(batch, n, d, use_mask, gpu_devic
         bn1.weight.copy_(prm[0]); bn1.bias.copy_(prm[1]); bn2.weight.copy_(prm[2]); bn2.bias.copy_(prm[3])
     bn1, bn2 = bn1.to(gpu_device), bn2.to(gpu_device)
     zg, eg = z.to(gpu_device), emb.to(gpu_device)
-    mg = None if mask is None else mask.to(gpu_device)
+    mg, mscale = (None if mask is None else mask.to(gpu_device)), 1.0
+    if use_mask == "u8":                            # byte keep-mask form: multiplier = keep * 1/(1-p)
+        mg, mscale = (mask > 0).to(torch.uint8).to(gpu_device), 1.0 / 0.8
     lw, lb = prm[4].to(gpu_device), prm[5].to(gpu_device)
-    out, stats = ops.head_train_fwd(zg, eg, bn1, bn2, lw, lb, mg, batch)
+    out, stats = ops.head_train_fwd(zg, eg, bn1, bn2, lw, lb, mg, batch, mscale)
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
     grads = ops.head_train_bwd(d_out.to(gpu_device), zg, eg, bn1.weight.detach(), bn1.bias.detach(),
-                               bn2.weight.detach(), bn2.bias.detach(), lw, mg, stats, 1e-5, 1e-5, batch)
+                               bn2.weight.detach(), bn2.bias.detach(), lw, mg, stats, 1e-5, 1e-5, batch, mscale)
     names = ["d_z", "d_emb", "d_bn1_w", "d_bn1_b", "d_bn2_w", "d_bn2_b", "d_lin_w", "d_lin_b"]
     for name, got, want in zip(names, grads, [t.grad for t in ref_in]):
         want = want.reshape(got.shape).numpy()
