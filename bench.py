@@ -289,6 +289,19 @@ def run():
         sev = harness.ShardedEvaluator(model, x, y, t * world, chunk=args.exchange_chunk)
         step = sev.step
 
+    # Kernel-level legs first, on every rank (their results are only reported by rank 0): K8 and fused
+    # roofline with HIP events, each after its own ~60 ms of sustained launches.  Besides producing the
+    # roofline numbers this leaves the GPU at steady clocks when the W warm-up steps begin — it needs ~50 ms
+    # of load after an idle period to get there (tools/probe_ramp.py), and W steps alone are a few ms.
+    launches_for = lambda b: max(12, min(64, 65536 // b))
+    sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sorted({batch, launch_batch, t})]
+    if world == 1 and args.sweep_max > t:       # the fraction at the largest per-GPU launch
+        xbig = torch.rand((args.sweep_max, N_SENSORS, WINDOW), device=device)     # 2 GB; xlin + z: 17 GB
+        sweep.append(k8_roofline(model, xbig, args.sweep_max, launches=12))
+        del xbig
+        torch.cuda.empty_cache()
+    fused_leg = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch))
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -328,18 +341,11 @@ def run():
                        if world > 1 else "single GPU"},
         }
     if rank == 0:
-        launches_for = lambda b: max(12, min(64, 65536 // b))
-        sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sorted({batch, launch_batch, t})]
-        if world == 1 and args.sweep_max > t:       # the fraction at the largest per-GPU launch
-            xbig = torch.rand((args.sweep_max, N_SENSORS, WINDOW), device=device)     # 2 GB; xlin + z: 17 GB
-            sweep.append(k8_roofline(model, xbig, args.sweep_max, launches=12))
-            del xbig
-            torch.cuda.empty_cache()
         # the launch size the timed region uses
         result["roofline"] = next(r for r in sweep if r["batch"] == launch_batch)
         result["roofline_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
                                      "launch_us": r["launch_us"]} for r in sweep]
-        result["roofline_fused"] = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch))
+        result["roofline_fused"] = fused_leg
         if args.coalesce > 1 and world == 1:      # transparency: the same step with one launch per logical minibatch
             ev1 = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams)
             for _ in range(args.warmup):
