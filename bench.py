@@ -248,7 +248,7 @@ def run():
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="side streams the forward launches rotate over")
-    ap.add_argument("--exchange-chunk", type=int, default=16384,
+    ap.add_argument("--exchange-chunk", type=int, default=32768,
                     help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
     ap.add_argument("--sweep-max", type=int, default=262144,
                     help="largest launch of the K8 roofline sweep (0 = stop at --ticks)")
