@@ -307,6 +307,9 @@ class GDN(nn.Module):
         gnn = layer.gnn
         c = self._constants()
         self.learned_graph = c.graph.topk                                   # GDN.py:159
+        if batch == 0 and not self.training:
+            # an empty minibatch: the reference's ops run on empty tensors and return [0, N]
+            return torch.empty((0, node_num), dtype=torch.float32, device=x.device)
         emb = self.embedding.weight
 
         if not self.training:

@@ -228,3 +228,13 @@ def test_eval_forward_against_float64_oracle(case, gpu_device):
     p64 = {k: (v.to(f64) if v.is_floating_point() else v) for k, v in p.items()}
     ref = gdn_oracle.forward(p64, x.to(f64), m["k"], m["out_layer_num"], graph=torch.from_numpy(data["learned_graph"]))
     np.testing.assert_allclose(out.cpu().numpy().astype(np.float64), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_empty_minibatch_returns_empty_prediction(gpu_device):
+    """Edge case: an eval forward of zero windows (a ragged last batch of size 0) gives a [0, N] tensor, as
+    the reference's op sequence does on empty tensors; the sensor graph is still published."""
+    model = random_params(27, 5, 5, 64, seed=1).to(gpu_device).eval()
+    with torch.no_grad():
+        out = model(torch.empty((0, 27, 5), device=gpu_device), None)
+    assert out.shape == (0, 27) and out.dtype == torch.float32
+    assert model.learned_graph.shape == (27, 5)
