@@ -286,8 +286,23 @@ def run():
     else:
         # N>1: windows shard by rank with no collective in the forward; the scoring exchange (all-to-all of
         # the radix keys by sensor) is issued per chunk of ticks and overlaps the forward of the following chunks
-        sev = harness.ShardedEvaluator(model, x, y, t * world, chunk=args.exchange_chunk)
-        step = sev.step
+        total = t * world
+        ok = torch.ones((1,), device=device)
+        try:
+            if os.environ.get("GDN_BENCH_FORCE_FALLBACK"):        # exercises the fallback on one GPU
+                raise RuntimeError("forced")
+            sev = harness.ShardedEvaluator(model, x, y, total, chunk=args.exchange_chunk)
+            sev.step()
+            torch.cuda.synchronize()
+            step = sev.step
+        except Exception as exc:                      # pragma: no cover - needs real peers to matter
+            print(f"[bench] ShardedEvaluator failed on rank {rank}: {exc!r}; falling back", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # every rank takes the same path
+        if float(ok.item()) == 0.0:
+            def step():
+                ev.forward_only()
+                return harness.distributed_anomaly(ev.pred, y, total, rehearse=args.rehearse_dist)
 
     # Kernel-level legs first, on every rank (their results are only reported by rank 0): K8 and fused
     # roofline with HIP events, each after its own ~60 ms of sustained launches.  Besides producing the
