@@ -238,3 +238,29 @@ def test_empty_minibatch_returns_empty_prediction(gpu_device):
         out = model(torch.empty((0, 27, 5), device=gpu_device), None)
     assert out.shape == (0, 27) and out.dtype == torch.float32
     assert model.learned_graph.shape == (27, 5)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_seeded_models_against_float64_oracle_with_own_graph(seed, gpu_device):
+    """Light fuzz at the bench shape: random parameters (non-trivial BatchNorm statistics, att_em), the
+    sensor graph learned by the HIP top-k itself.  (1) wherever the k-th / (k+1)-th cosine gap of a sensor
+    exceeds 1e-6 the HIP neighbour set equals the float64 oracle's; (2) with that graph the eval forward is
+    within 2e-6 (+1e-5 relative) of the float64 oracle."""
+    n, w, k, d, b = 127, 15, 30, 64, 4
+    model = random_params(n, w, k, d, seed=seed).to(gpu_device).eval()
+    p = {key: v.detach().cpu() for key, v in model.state_dict().items()}
+    x = torch.rand((b, n, w), generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        out = model(x.to(gpu_device), None)
+    graph = model.learned_graph.cpu()
+    f64 = torch.float64
+    p64 = {key: (v.to(f64) if v.is_floating_point() else v) for key, v in p.items()}
+    cos = gdn_oracle.cosine_matrix(p64["embedding.weight"])
+    srt = torch.sort(cos, dim=1, descending=True)
+    clear = (srt.values[:, k - 1] - srt.values[:, k]) > 1e-6
+    assert clear.float().mean() > 0.9
+    want_sets = srt.indices[:, :k]
+    for i in torch.nonzero(clear).flatten().tolist():
+        assert set(graph[i].tolist()) == set(want_sets[i].tolist()), i
+    ref = gdn_oracle.forward(p64, x.to(f64), k, graph=graph)
+    np.testing.assert_allclose(out.cpu().numpy().astype(np.float64), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
