@@ -264,3 +264,28 @@ def test_seeded_models_against_float64_oracle_with_own_graph(seed, gpu_device):
         assert set(graph[i].tolist()) == set(want_sets[i].tolist()), i
     ref = gdn_oracle.forward(p64, x.to(f64), k, graph=graph)
     np.testing.assert_allclose(out.cpu().numpy().astype(np.float64), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_integration_md_ctypes_stub_runs(gpu_device):
+    """INTEGRATION.md §B shows the ctypes binding a reference maintainer would paste into models/GDN.py.
+    Execute that very snippet (library path made absolute) as the forward of a model object and compare
+    with the packaged forward: the documentation must stay runnable."""
+    import os
+    import re
+    import types
+    from gdn_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libgdn_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    model = random_params(51, 15, 15, 64, seed=21).to(gpu_device).eval()     # SWaT's 51 sensors
+    x = torch.rand((16, 51, 15), device=gpu_device)
+    with torch.no_grad():
+        want = model(x, None)
+        got = types.MethodType(ns["forward"], model)(x, None)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(model.learned_graph, model._constants().graph.topk)
