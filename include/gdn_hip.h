@@ -197,7 +197,9 @@ int gdn_rev_pitch(int n);
 int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n, int k,
                       uint32_t* rent, int32_t* rlen, void* stream);
 
-/* x[BN,w], d_xlin[BN,d], d_si/d_sj[BN] -> d_lin_w[d,w] (direct term), d_a[2,64]
+/* Backward of gdn_project_fwd, i.e. of `x = self.lin(x)` (models/graph_layer.py:56) and of the
+ * folded logit scalars (graph_layer.py:94-104):
+ * x[BN,w], d_xlin[BN,d], d_si/d_sj[BN] -> d_lin_w[d,w] (direct term), d_a[2,64]
  * (grads of a_i, a_j), d_c[2,n] (grads of c_i, c_j); outputs are written, not accumulated.
  * workspace: gdn_project_bwd_workspace_bytes(n, w, d) bytes (one partial row per workgroup). */
 long long gdn_project_bwd_workspace_bytes(int n, int w, int d);
