@@ -22,10 +22,12 @@ from . import ops
 
 
 # --------------------------------------------------------------------------- eval loop
-def test(model, dataloader, device=None):
+def test(model, dataloader, device=None, as_tensors: bool = False):
     """Mirror of the reference test() (test.py:21-79).  Returns (avg_loss, [predictions, ground
     truth, labels]) with the three results as python lists, exactly like the reference; per-batch
-    losses stay on the device and are read once at the end (the reference syncs every batch)."""
+    losses stay on the device and are read once at the end (the reference syncs every batch).
+    `as_tensors=True` keeps the three results as device tensors [T, N] (gdn_amd.evaluate accepts
+    them directly): the `.tolist()` of the reference costs seconds at T = 10^5 windows."""
     device = device or next(model.parameters()).device
     model.eval()
     preds, gts, labs, losses = [], [], [], []
@@ -40,7 +42,8 @@ def test(model, dataloader, device=None):
     avg_loss = float(torch.stack(losses).double().sum().item() / len(losses)) if losses else 0.0
     if not preds:
         return avg_loss, [[], [], []]
-    return avg_loss, [torch.cat(preds).tolist(), torch.cat(gts).tolist(), torch.cat(labs).tolist()]
+    out = [torch.cat(preds), torch.cat(gts), torch.cat(labs)]
+    return avg_loss, (out if as_tensors else [t.tolist() for t in out])
 
 
 def train(model=None, save_path="", config=None, train_dataloader=None, val_dataloader=None, use_graph=False,

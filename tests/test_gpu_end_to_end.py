@@ -48,6 +48,9 @@ def test_train_eval_score_finds_injected_fault(gpu_device):
     tloader = [(xte[s:s + 256], yte[s:s + 256], labels[s:s + 256], None) for s in range(0, len(xte), 256)]
     _loss, result = harness.test(model, tloader)
     scores, _ = get_full_err_scores(result)
+    _loss_t, result_t = harness.test(model, tloader, as_tensors=True)          # device tensors, no .tolist()
+    scores_t, _ = get_full_err_scores(result_t)
+    assert _loss_t == _loss and np.array_equal(scores_t, scores)
     assert scores.shape == (N, len(xte))
     anomaly = get_top1_anomaly(scores)
     lab = labels.numpy().astype(bool)
