@@ -75,21 +75,33 @@ __global__ __launch_bounds__(256) void gdn_graph_kernel(
   emit_list(rank_of, i, n, k, pitch, nbr + (size_t)i * pitch, deg + i);
 }
 
-// Same list build from a given [n,k] top-k table.
+// Same list build from a given [n,k] top-k table.  The table is caller data: entries outside
+// [0, n) and repeated entries are dropped (first occurrence wins), so every slot below deg is
+// written and deg counts what was kept — the aggregation kernels never see an unwritten index.
 __global__ __launch_bounds__(256) void gdn_graph_from_topk_kernel(
     const int64_t* __restrict__ topk_idx, int n, int k, int pitch, uint16_t* __restrict__ nbr,
     int32_t* __restrict__ deg) {
   extern __shared__ float smem_graph[];
-  int* rank_of = reinterpret_cast<int*>(smem_graph);  // [n]
+  int* rank_of = reinterpret_cast<int*>(smem_graph);  // [n]: lowest rank naming j, or k
   const int i = blockIdx.x;
   for (int j = threadIdx.x; j < n; j += blockDim.x) rank_of[j] = k;  // "not in top-k"
   __syncthreads();
   for (int r = threadIdx.x; r < k; r += blockDim.x) {
     const int64_t j = topk_idx[(size_t)i * k + r];
-    if (j >= 0 && j < n) rank_of[j] = r;
+    if (j >= 0 && j < n) atomicMin(&rank_of[j], r);
   }
   __syncthreads();
-  emit_list(rank_of, i, n, k, pitch, nbr + (size_t)i * pitch, deg + i);
+  if (threadIdx.x == 0) {   // once per graph, k <= 1023: a serial compaction keeps rank order
+    uint16_t* row = nbr + (size_t)i * pitch;
+    int p = 0;
+    for (int r = 0; r < k; ++r) {
+      const int64_t j = topk_idx[(size_t)i * k + r];
+      if (j >= 0 && j < n && j != i && rank_of[j] == r) row[p++] = (uint16_t)j;
+    }
+    row[p++] = (uint16_t)i;   // models/graph_layer.py:61-63: self loop appended last
+    deg[i] = p;
+    for (; p < pitch; ++p) row[p] = (uint16_t)n;
+  }
 }
 
 // a_i = lin^T att_i, a_j = lin^T att_j (zero padded to 64), c_i[s] = v_s.att_em_i, c_j[s].

@@ -578,4 +578,8 @@ class GraphedTrainStep:
         if self._split:
             self._all_reduce()                           # the only eager op of a multi-rank step
             self._graphs[1].replay()
+        # a replay writes parameters and BatchNorm statistics through raw pointers: no Python forward
+        # runs and no version counter moves, so the model's cached eval constants (sensor graph,
+        # attention terms, BatchNorm folds) must be dropped here or eval after training serves stale ones
+        self.model.invalidate_constants()
         return self.loss

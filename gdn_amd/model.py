@@ -237,8 +237,10 @@ class GDN(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def invalidate_constants(self):
-        """Forget the cached sensor graph / folded constants (see `_constants`)."""
+        """Forget the cached sensor graph / folded constants (see `_constants`).  The generation counter is
+        part of the cache key, so holders of captured HIP graphs (harness.SeriesEvaluator) see the change too."""
         self._consts = None
+        self._generation = getattr(self, "_generation", 0) + 1
 
     def _param_key(self):
         ps = getattr(self, "_key_tensors", None)
@@ -247,7 +249,7 @@ class GDN(nn.Module):
                   *self.gnn_layers[0].bn.buffers(), *self.bn_outlayer_in.buffers(), *self.out_layer.parameters()]
             self._key_tensors = ps
         inj = None if self.injected_graph is None else (self.injected_graph.data_ptr(), self.injected_graph._version)
-        return tuple((p.data_ptr(), p._version) for p in ps) + (self.training, inj)
+        return tuple((p.data_ptr(), p._version) for p in ps) + (self.training, inj, getattr(self, "_generation", 0))
 
     def _constants(self) -> _EvalConstants:
         """Sensor graph + folded per-forward constants.  In eval they are cached and rebuilt when a

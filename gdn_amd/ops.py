@@ -68,6 +68,8 @@ def topk_graph(emb: torch.Tensor, k: int, want_cos: bool = False) -> SensorGraph
 def graph_from_topk(topk: torch.Tensor) -> SensorGraph:
     topk = _chk(topk, torch.int64, "topk")
     n, k = topk.shape
+    if k > 0 and (int(topk.min()) < 0 or int(topk.max()) >= n):     # caller data: one sync, once per graph
+        raise ValueError(f"injected top-k table has entries outside [0, {n})")
     nbr = torch.empty((n, nbr_pitch(k)), dtype=torch.uint16, device=topk.device)
     deg = torch.empty((n,), dtype=torch.int32, device=topk.device)
     _lib.call("gdn_graph_from_topk", _ptr(topk), n, k, _ptr(nbr), _ptr(deg), _stream())

@@ -176,6 +176,34 @@ def run_case(name, *, seed, b, n, w, k, d=64, out_layers=1, inter=256, x=None, y
     return model
 
 
+def run_eval_only_case(name, *, seed, b, n, w, k, d=64, x=None, raw=None, note="", min_gap=5e-5):
+    """A BASELINE config at its full batch: only what a batch-sized fixture can afford to keep — the
+    parameters, the learned graph and the reference's eval output.  When `x` is None the input is
+    torch.rand under `Generator().manual_seed(x_seed)` (regenerated by the test; its float64 sum is
+    stored to catch a drifting RNG)."""
+    model = build_model(seed, n, w, k, d, 1, 256, None)
+    while cosine_gap(model, k) < min_gap:
+        seed += 100
+        model = build_model(seed, n, w, k, d, 1, 256, None)
+    out = {"meta_bnwkd": np.array([b, n, w, k, d, 1, 256], dtype=np.int64),
+           "cos_gap": np.array(cosine_gap(model, k)), "seed": np.array(seed)}
+    if x is None:
+        x_seed = seed + 2000
+        x = torch.rand((b, n, w), generator=torch.Generator().manual_seed(x_seed))
+        out["x_seed"] = np.array(x_seed)
+        out["x_sum"] = np.array(float(x.double().sum()))
+    else:
+        out["raw"] = raw                              # [N, w+b] series slice; windows are rebuilt from it
+    out.update(state_arrays(model.state_dict(), "p/"))
+    model.eval()
+    with torch.no_grad():
+        pred = model(x, torch.zeros((b, 2, 4)))
+    out["eval_out"] = pred.numpy().copy()
+    out["learned_graph"] = model.learned_graph.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: out {out['eval_out'].shape} cos_gap {out['cos_gap']:.3e} {note}")
+
+
 def msl_slice(w, b):
     """Config 1 input: the first w+b rows of the reference's demo test series."""
     import pandas as pd
@@ -341,8 +369,20 @@ def performance_cases():
         print(f"{name}: best {out['best_top1']} val {out['val_top1']}")
 
 
+def full_batch_cases():
+    """BASELINE.json configs as worded, at their stated batch (round 2)."""
+    xs, _ys, raw = msl_slice(15, 128)
+    run_eval_only_case("cfg0_msl27_w15_k20_b128", seed=15, b=128, n=27, w=15, k=20, x=xs, raw=raw.astype(np.float32),
+                       note="(configs[0] at slide_win=15: first 143 rows of data/msl/test.csv)")
+    run_eval_only_case("cfg1_fc64_w15_k64_b128", seed=11, b=128, n=64, w=15, k=64)
+    run_eval_only_case("cfg2_swat127_w15_k30_b512", seed=12, b=512, n=127, w=15, k=30)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "full-batch":
+        full_batch_cases()
+        return
     xs, ys, raw = msl_slice(5, 8)
     run_case("msl_demo_w5_k5", seed=5, b=8, n=27, w=5, k=5, x=xs, y=ys,
              note="(input = first 13 rows of data/msl/test.csv)")
@@ -360,6 +400,7 @@ def main():
     train_curve_case()
     score_cases()
     performance_cases()
+    full_batch_cases()
 
 
 if __name__ == "__main__":

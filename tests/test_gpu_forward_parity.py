@@ -189,6 +189,49 @@ def test_windows_read_from_the_raw_series_equal_materialised_windows(n, w, k, d,
     assert torch.equal(part, want[37:138])
 
 
+@pytest.mark.parametrize("case", ["cfg0_msl27_w15_k20_b128", "cfg1_fc64_w15_k64_b128", "cfg2_swat127_w15_k30_b512"])
+def test_baseline_configs_as_worded_at_full_batch(case, gpu_device):
+    """BASELINE.json configs[0] (msl, 27 sensors, slide_win=15, k=20, batch 128), configs[1] (64 sensors fully
+    connected, batch 128) and configs[2] (127 sensors, k=30, batch 512): GDN.forward at the stated batch
+    against the output of the reference's own model code (fixture), graph learned on the GPU."""
+    from test_oracle_golden import full_batch_input
+    data, p = load_golden(case)
+    m = meta(data)
+    model = build_model(p, m, gpu_device)
+    x = full_batch_input(data).to(gpu_device)
+    with torch.no_grad():
+        out = model(x, torch.zeros((m["b"], 2, 4), device=gpu_device))
+    if m["k"] < m["n"]:
+        np.testing.assert_array_equal(model.learned_graph.cpu().numpy(), data["learned_graph"])
+    np.testing.assert_allclose(out.cpu().numpy(), data["eval_out"], atol=TOL, rtol=0)
+    # the staged pipeline (what training and out_layer_num > 1 use) at the same batch
+    from gdn_amd import ops
+    c = model._constants()
+    gnn, lin = model.gnn_layers[0].gnn, model.out_layer.mlp[0]
+    xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
+    z, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, m["b"], want_alpha=False)
+    out2, _ = ops.head_fwd(z, model.embedding.weight, c.bn1, c.bn2, lin.weight, lin.bias, m["b"])
+    np.testing.assert_allclose(out2.cpu().numpy(), data["eval_out"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("case,raw_case", [("msl_demo_w5_k5", "msl_raw_slice"),
+                                           ("cfg0_msl27_w15_k20_b128", None)])
+def test_forward_series_on_the_reference_demo_series_against_golden(case, raw_case, gpu_device):
+    """SURVEY §8f-1 against GOLDEN data (not HIP-vs-HIP): the windows the reference's TimeDataset builds
+    from data/msl/test.csv are built inside the kernel from the raw [N, T] slice, and the predictions are
+    compared with what the reference's model produced on the host-built windows."""
+    data, p = load_golden(case)
+    m = meta(data)
+    raw = load_golden(raw_case)[0]["raw"] if raw_case else data["raw"]
+    series = torch.from_numpy(raw.astype(np.float32)).to(gpu_device)
+    assert series.shape == (m["n"], m["w"] + m["b"])
+    model = build_model(p, m, gpu_device)
+    got = model.forward_series(series, 0, m["b"])
+    np.testing.assert_allclose(got.cpu().numpy(), data["eval_out"], atol=TOL, rtol=0)
+    part = model.forward_series(series, 3, m["b"] - 3)
+    np.testing.assert_allclose(part.cpu().numpy(), data["eval_out"][3:], atol=TOL, rtol=0)
+
+
 def test_262144_window_launch_equals_small_launches(gpu_device):
     """SURVEY §8d's largest launch (xlin alone is 8.5 GB: every row offset needs 64-bit addressing): the
     staged kernels and the fused forward on 262144 windows give, bit for bit, what 512-window launches of

@@ -370,3 +370,74 @@ def test_train_step_against_float64_oracle(case, gpu_device):
         want = leaf[name].grad.numpy()
         np.testing.assert_allclose(prm.grad.cpu().numpy().astype(np.float64), want, atol=2e-6, rtol=1e-5,
                                    err_msg=name)
+
+
+def test_graph_mode_with_even_batches_keeps_validation_fresh(gpu_device, tmp_path):
+    """Every batch is full-size, so a graph-mode epoch runs NO Python forward in train mode: the
+    validation pass after each epoch must still see the parameters the replays wrote (the eval
+    constants cache is keyed on versions a replay never bumps — GraphedTrainStep.step invalidates it).
+    Same per-step losses, validation-selected checkpoint and early-stop bookkeeping as the eager loop."""
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    g = torch.Generator().manual_seed(12)
+    xs, ys = torch.rand((128, 27, 10), generator=g), torch.rand((128, 27), generator=g)
+    loader = [(xs[s:s + 64], ys[s:s + 64], torch.zeros(64), None) for s in range(0, 128, 64)]
+    val = [(xs[:32] * 0.5, ys[:32], torch.zeros(32), None)]
+    seen = {}
+    real_test = harness.test
+
+    def spy(model, dataloader, device=None, **kw):
+        loss, res = real_test(model, dataloader, device, **kw)
+        seen.setdefault(spy.mode, []).append(loss)
+        return loss, res
+    harness.test = spy
+    try:
+        out = {}
+        for mode in (False, True):
+            spy.mode = mode
+            model = random_params(27, 10, 8, 64, seed=5).to(gpu_device)
+            model.dp.p = 0.0
+            path = str(tmp_path / f"best_{mode}.pt")
+            losses = harness.train(model, path, {"epoch": 3}, loader, val, use_graph=mode)
+            out[mode] = (losses, torch.load(path, weights_only=True))
+    finally:
+        harness.test = real_test
+    assert len(seen[False]) == len(seen[True]) == 3
+    assert len(set(seen[True])) == 3, "validation loss did not move: stale eval constants"
+    np.testing.assert_allclose(seen[True], seen[False], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out[True][0], out[False][0], atol=2e-5, rtol=0)
+    for key, val_e in out[False][1].items():
+        tol = 2e-2 if key.endswith("gnn.bias") or key.endswith("0.bn.running_mean") else 1e-4
+        np.testing.assert_allclose(val_e.cpu().numpy(), out[True][1][key].cpu().numpy(), atol=tol, err_msg=key)
+
+
+def test_eval_after_replays_equals_a_fresh_model_with_the_same_state(gpu_device):
+    """N replays, then eval (model.forward and a SeriesEvaluator that had captured its graph BEFORE the
+    training): both must equal a freshly built model loaded with the trained state_dict."""
+    from gdn_amd import GDN, harness
+    from test_gpu_forward_parity import random_params
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand((64, 27, 10), generator=g).to(gpu_device)
+    y = torch.rand((64, 27), generator=g).to(gpu_device)
+    model = random_params(27, 10, 8, 64, seed=6).to(gpu_device)
+    model.dp.p = 0.0
+    ev = harness.SeriesEvaluator(model, x, y, batch=32, use_graph=True, streams=1)
+    before = ev.step().clone()                       # captures the eval graph with the untrained constants
+    step = harness.GraphedTrainStep(model, 64)
+    step.x.copy_(x)
+    step.y.copy_(y)
+    for _ in range(5):
+        step.step()
+    model.eval()
+    with torch.no_grad():
+        got = model(x, None)
+    after = ev.step().clone()
+    fresh = GDN([torch.zeros((2, 1), dtype=torch.long)], 27, dim=64, input_dim=10, topk=8)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    fresh = fresh.to(gpu_device).eval()
+    with torch.no_grad():
+        want = fresh(x, None)
+    assert float((want - got).abs().max()) == 0.0
+    ev2 = harness.SeriesEvaluator(fresh, x, y, batch=32, use_graph=False, streams=1)
+    np.testing.assert_array_equal(after.cpu().numpy(), ev2.step().cpu().numpy())
+    assert not torch.equal(before, after)

@@ -114,3 +114,31 @@ def test_threshold_sweep_oracle_matches_reference_evaluate(case):
         normal = scores[:, : scores.shape[1] // 6]
         np.testing.assert_allclose(score_oracle.val_performance(scores, normal, labels, topk), data[f"val_top{topk}"],
                                    rtol=1e-12, atol=0)
+
+
+FULL_BATCH_CASES = ["cfg0_msl27_w15_k20_b128", "cfg1_fc64_w15_k64_b128", "cfg2_swat127_w15_k30_b512"]
+
+
+def full_batch_input(data):
+    """Input of a full-batch fixture (tests/golden/make_golden.py: run_eval_only_case): windows rebuilt from
+    the stored raw series slice (datasets/TimeDataset.py:46-57), or torch.rand under the stored seed."""
+    b, n, w = (int(v) for v in data["meta_bnwkd"][:3])
+    if "raw" in data:
+        raw = torch.from_numpy(data["raw"].astype(np.float32))
+        return torch.stack([raw[:, t - w:t] for t in range(w, w + b)])
+    x = torch.rand((b, n, w), generator=torch.Generator().manual_seed(int(data["x_seed"])))
+    assert float(x.double().sum()) == float(data["x_sum"]), "torch.rand stream changed: regenerate the fixture"
+    return x
+
+
+@pytest.mark.parametrize("case", FULL_BATCH_CASES)
+def test_full_batch_configs_oracle_matches_reference(case):
+    """BASELINE configs[0..2] as worded, at their stated batch: oracle vs the reference's eval output."""
+    data, p = load_golden(case)
+    m = meta(data)
+    x = full_batch_input(data)
+    with torch.no_grad():
+        r = gdn_oracle.forward(p, x, m["k"])
+    if m["k"] < m["n"]:
+        assert torch.equal(r["learned_graph"], torch.from_numpy(data["learned_graph"]))
+    np.testing.assert_allclose(r["out"].numpy(), data["eval_out"], atol=FP32_TOL, rtol=0)
