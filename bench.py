@@ -246,6 +246,7 @@ def run():
     ap.add_argument("--coalesce", type=int, default=8,
                     help="consecutive minibatches of the resident series sent as one launch (1 = per-batch launches)")
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="side streams the forward launches rotate over")
     ap.add_argument("--exchange-chunk", type=int, default=32768,
@@ -283,26 +284,18 @@ def run():
                                  coalesce=args.coalesce)
     if world == 1 and not args.rehearse_dist:
         step = ev.step
+        step_impl = "SeriesEvaluator: forward launches + device scoring, one HIP graph replay per step"
     else:
         # N>1: windows shard by rank with no collective in the forward; the scoring exchange (all-to-all of
-        # the radix keys by sensor) is issued per chunk of ticks and overlaps the forward of the following chunks
+        # the radix keys by sensor) is issued per chunk of ticks and overlaps the forward of the following
+        # chunks.  No fallback: a rank that cannot build or run this step fails the whole job (a silently
+        # different timed path would be reported under this path's label).
         total = t * world
-        ok = torch.ones((1,), device=device)
-        try:
-            if os.environ.get("GDN_BENCH_FORCE_FALLBACK"):        # exercises the fallback on one GPU
-                raise RuntimeError("forced")
-            sev = harness.ShardedEvaluator(model, x, y, total, chunk=args.exchange_chunk)
-            sev.step()
-            torch.cuda.synchronize()
-            step = sev.step
-        except Exception as exc:                      # pragma: no cover - needs real peers to matter
-            print(f"[bench] ShardedEvaluator failed on rank {rank}: {exc!r}; falling back", file=sys.stderr)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # every rank takes the same path
-        if float(ok.item()) == 0.0:
-            def step():
-                ev.forward_only()
-                return harness.distributed_anomaly(ev.pred, y, total, rehearse=args.rehearse_dist)
+        sev = harness.ShardedEvaluator(model, x, y, total, chunk=args.exchange_chunk)
+        sev.step()
+        torch.cuda.synchronize()
+        step = sev.step
+        step_impl = "ShardedEvaluator: eager launches, async all_to_all_single per chunk + one all_gather"
 
     # Kernel-level legs first, on every rank (their results are only reported by rank 0): K8 and fused
     # roofline with HIP events, each after its own ~60 ms of sustained launches.  Besides producing the
@@ -317,24 +310,43 @@ def run():
         torch.cuda.empty_cache()
     fused_leg = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch))
 
+    def timed(fn, steps):
+        """`steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    def preroll(fn, ms=120.0):
+        """>= `ms` of back-to-back steps right before a timed region (not part of --warmup): this GPU needs
+        ~50 ms of sustained load after an idle period to reach its steady clocks (tools/probe_ramp.py), and a
+        20-step region is 14 ms.  The step count is agreed across ranks (the N>1 step contains collectives)."""
+        per_step = timed(fn, 8) / 8
+        for _ in range(int(ms * 1e-3 / max(per_step, 1e-6)) + 1):
+            fn()
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # the timed region: EXACTLY --steps steps, repeated (each repeat after its own pre-roll); the median
+    # repeat is the reported one, all of them are listed
+    repeats = []
+    for _ in range(max(1, args.repeats)):
+        preroll(step)
+        repeats.append(timed(step, args.steps))
+    elapsed = sorted(repeats)[len(repeats) // 2]
 
     result = None
     if rank == 0:
@@ -349,12 +361,13 @@ def run():
                        "sensors": N_SENSORS, "window": WINDOW, "topk": TOPK, "dim": DIM, "out_layer_num": 1,
                        "batch": batch, "batches_per_launch": max(1, args.coalesce),
                        "windows_per_launch": launch_batch, "windows_per_rank_per_step": t, "storage": "fp32",
-                       "hip_graph": not args.no_graph, "forward_streams": args.streams,
+                       "hip_graph": not args.no_graph, "forward_streams": args.streams, "step_impl": step_impl,
                        "parallelism": f"windows sharded over {world} rank(s), no forward collective; scoring keys "
                                       f"all-to-all by sensor in chunks of {args.exchange_chunk} ticks (async, overlapping "
                                       "the forward) + one all-gather"
                        if world > 1 else "single GPU"},
         }
+        result["timed_regions_ms_per_step"] = [round(1e3 * r / args.steps, 4) for r in repeats]
     if rank == 0:
         # the launch size the timed region uses
         result["roofline"] = next(r for r in sweep if r["batch"] == launch_batch)
@@ -365,12 +378,8 @@ def run():
             ev1 = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams)
             for _ in range(args.warmup):
                 ev1.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                ev1.step()
-            torch.cuda.synchronize()
-            result["value_per_batch_launches"] = round(t * args.steps / (time.perf_counter() - t1), 1)
+            preroll(ev1.step)
+            result["value_per_batch_launches"] = round(t * args.steps / timed(ev1.step, args.steps), 1)
     if rank == 0 and world == 1:
         # the same step with the windows built in-kernel from the raw [N, T+W] series
         raw = torch.rand((N_SENSORS, t + WINDOW), generator=torch.Generator().manual_seed(7)).to(device)
@@ -379,12 +388,8 @@ def run():
                                       series=raw)
         for _ in range(args.warmup):
             ev2.step()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            ev2.step()
-        torch.cuda.synchronize()
-        result["value_windows_from_raw_series"] = round(t * args.steps / (time.perf_counter() - t2), 1)
+        preroll(ev2.step)
+        result["value_windows_from_raw_series"] = round(t * args.steps / timed(ev2.step, args.steps), 1)
         result["train_step"] = train_step_line(device, n=x.shape[1], w=x.shape[2], batch=args.batch)
         if not args.skip_cpu:
             result["cpu_baseline"] = cpu_baseline(params)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gdn_hip.h"
 
@@ -24,6 +25,23 @@ static inline int gdn_cu_count() {
     if (cus <= 0) cus = 256;
   }
   return cus;
+}
+
+// gdn_forward_dense.hip: the matrix-core aggregation path (n <= 127, d = 64); x is fp32 or bf16 bits
+bool gdn_dense_supported(int n, int w, int d, int k);
+int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int series_first, const float* lin_w,
+                            const float* node_terms, const uint16_t* nbr, const float* gnn_bias,
+                            const float* emb, const float* bn1, const float* bn2, const float* out_w,
+                            const float* out_b, int batch, int n, int w, int d, int k, float* out,
+                            hipStream_t stream);
+// run-time choice between the two fused forward implementations: GDN_FUSED_PATH=valu keeps the fp32 VALU
+// row-gather kernel for every shape (read once per process)
+static inline bool gdn_use_dense_path() {
+  static const int use = [] {
+    const char* e = getenv("GDN_FUSED_PATH");
+    return (e && e[0] == 'v') ? 0 : 1;
+  }();
+  return use != 0;
 }
 
 // ---- DPP within a 16-lane row ------------------------------------------------------
