@@ -34,6 +34,11 @@ int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int se
                             const float* emb, const float* bn1, const float* bn2, const float* out_w,
                             const float* out_b, int batch, int n, int w, int d, int k, float* out,
                             hipStream_t stream);
+int gdn_dense_attn_aggregate(const void* xlin, int is_bf16, const float* s_i, const float* s_j, const uint16_t* nbr,
+                             const float* bias, int batch, int n, int d, int k, void* z, float* alpha,
+                             hipStream_t stream);
+int gdn_dense_project(const void* x, int is_bf16, const float* lin_w, const float* node_terms, int batch, int n,
+                      int w, int d, void* xlin, float* s_i, float* s_j, hipStream_t stream);
 // run-time choice between the two fused forward implementations: GDN_FUSED_PATH=valu keeps the fp32 VALU
 // row-gather kernel for every shape (read once per process)
 static inline bool gdn_use_dense_path() {

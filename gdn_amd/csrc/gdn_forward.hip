@@ -901,8 +901,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
 
 // ------------------------------------------------------------------ head (staged eval path)
 // z[BN, d] -> out[BN]; 16 lanes per row (VEC columns each; d = 128: two passes per lane).
-template <int D>
-__global__ __launch_bounds__(256) void gdn_head_kernel(const float* __restrict__ z,
+__device__ __forceinline__ float head_load(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float head_load(const uint16_t* p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+
+template <int D, typename ZT>
+__global__ __launch_bounds__(256) void gdn_head_kernel(const ZT* __restrict__ z,
                                                        const float* __restrict__ emb,
                                                        const float* __restrict__ bn1,
                                                        const float* __restrict__ bn2,
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256) void gdn_head_kernel(const float* __restrict__
       const int s = row % n;
 #pragma unroll
       for (int v = 0; v < CPL; ++v) {
-        zv[u][v] = z[(size_t)row * D + d0 + v];
+        zv[u][v] = head_load(z, (size_t)row * D + d0 + v);
         ev[u][v] = emb[(size_t)s * D + d0 + v];
       }
     }
@@ -1122,6 +1125,8 @@ int dispatch_window(const Plan& pl, const Args& a, int threads, hipStream_t stre
 extern "C" int gdn_project_fwd(const float* x, const float* lin_w, const float* node_terms, int batch,
                                int n, int w, int d, float* xlin, float* s_i, float* s_j, void* stream) {
   if (!x || !lin_w || !node_terms || !xlin || !s_i || !s_j) return GDN_ERR_ARG;
+  if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, w, d, 1))
+    return gdn_dense_project(x, 0, lin_w, node_terms, batch, n, w, d, xlin, s_i, s_j, (hipStream_t)stream);
   Plan pl; int threads;
   const int rc = make_plan(MODE_PROJECT, batch, n, w, d, 0, &pl, &threads);
   if (rc != GDN_OK) return rc;
@@ -1136,6 +1141,8 @@ extern "C" int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const
                                       int batch, int n, int d, int k, float* z, float* alpha,
                                       void* stream) {
   if (!xlin || !s_i || !s_j || !nbr || !deg || !bias || !z) return GDN_ERR_ARG;
+  if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k))
+    return gdn_dense_attn_aggregate(xlin, 0, s_i, s_j, nbr, bias, batch, n, d, k, z, alpha, (hipStream_t)stream);
   Plan pl; int threads;
   const int rc = make_plan(MODE_ATTN, batch, n, 0, d, k, &pl, &threads);
   if (rc != GDN_OK) return rc;
@@ -1196,20 +1203,61 @@ extern "C" int gdn_forward_fused_series(const float* series, int series_len, int
   return dispatch_window<MODE_FUSED>(pl, a, threads, (hipStream_t)stream);
 }
 
-extern "C" int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
-                            const float* bn2_affine, const float* out_w, const float* out_b, int batch,
-                            int n, int d, float* out, float* h2, void* stream) {
+template <typename ZT>
+static int head_launch(const ZT* z, const float* emb, const float* bn1_affine, const float* bn2_affine,
+                       const float* out_w, const float* out_b, int batch, int n, int d, float* out, float* h2,
+                       void* stream) {
   if (!z || !emb || !bn1_affine || !bn2_affine || !out_w || !out_b || !out || batch <= 0 || n <= 0)
     return GDN_ERR_ARG;
   const int rows = batch * n;
   const int grid = min((rows + 63) / 64, gdn_cu_count() * 8);
   hipStream_t st = (hipStream_t)stream;
   switch (d) {
-    case 16: hipLaunchKernelGGL(gdn_head_kernel<16>, dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
-    case 32: hipLaunchKernelGGL(gdn_head_kernel<32>, dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
-    case 64: hipLaunchKernelGGL(gdn_head_kernel<64>, dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
-    case 128: hipLaunchKernelGGL(gdn_head_kernel<128>, dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
+    case 16: hipLaunchKernelGGL((gdn_head_kernel<16, ZT>), dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
+    case 32: hipLaunchKernelGGL((gdn_head_kernel<32, ZT>), dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
+    case 64: hipLaunchKernelGGL((gdn_head_kernel<64, ZT>), dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
+    case 128: hipLaunchKernelGGL((gdn_head_kernel<128, ZT>), dim3(grid), dim3(256), 0, st, z, emb, bn1_affine, bn2_affine, out_w, out_b, rows, n, out, h2); break;
     default: return GDN_ERR_UNSUPPORTED;
   }
   return gdn_launch_status();
+}
+
+extern "C" int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
+                            const float* bn2_affine, const float* out_w, const float* out_b, int batch,
+                            int n, int d, float* out, float* h2, void* stream) {
+  return head_launch<float>(z, emb, bn1_affine, bn2_affine, out_w, out_b, batch, n, d, out, h2, stream);
+}
+
+extern "C" int gdn_head_fwd_bf16(const uint16_t* z, const float* emb, const float* bn1_affine,
+                                 const float* bn2_affine, const float* out_w, const float* out_b, int batch,
+                                 int n, int d, float* out, float* h2, void* stream) {
+  return head_launch<uint16_t>(z, emb, bn1_affine, bn2_affine, out_w, out_b, batch, n, d, out, h2, stream);
+}
+
+// ---- bf16 storage (BASELINE configs[2] / [4]): x, xlin and z are bf16 in HBM; logits, softmax and every
+// accumulation stay fp32.  Matrix-core path only (n <= 127, d = 64): anything else is refused.
+extern "C" int gdn_project_fwd_bf16(const uint16_t* x, const float* lin_w, const float* node_terms, int batch,
+                                    int n, int w, int d, uint16_t* xlin, float* s_i, float* s_j, void* stream) {
+  if (!x || !lin_w || !node_terms || !xlin || !s_i || !s_j || batch <= 0) return GDN_ERR_ARG;
+  return gdn_dense_project(x, 1, lin_w, node_terms, batch, n, w, d, xlin, s_i, s_j, (hipStream_t)stream);
+}
+
+extern "C" int gdn_attn_aggregate_fwd_bf16(const uint16_t* xlin, const float* s_i, const float* s_j,
+                                           const uint16_t* nbr, const int32_t* deg, const float* bias,
+                                           int batch, int n, int d, int k, uint16_t* z, float* alpha,
+                                           void* stream) {
+  if (!xlin || !s_i || !s_j || !nbr || !deg || !bias || !z || batch <= 0) return GDN_ERR_ARG;
+  return gdn_dense_attn_aggregate(xlin, 1, s_i, s_j, nbr, bias, batch, n, d, k, z, alpha, (hipStream_t)stream);
+}
+
+extern "C" int gdn_forward_fused_bf16(const uint16_t* x, const float* lin_w, const float* node_terms,
+                                      const uint16_t* nbr, const int32_t* deg, const float* gnn_bias,
+                                      const float* emb, const float* bn1_affine, const float* bn2_affine,
+                                      const float* out_w, const float* out_b, int batch, int n, int w, int d,
+                                      int k, float* out, void* stream) {
+  if (!x || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine || !bn2_affine ||
+      !out_w || !out_b || !out || batch <= 0)
+    return GDN_ERR_ARG;
+  return gdn_dense_forward_fused(x, 1, 0, 0, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine, bn2_affine,
+                                 out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
 }

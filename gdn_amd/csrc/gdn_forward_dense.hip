@@ -45,6 +45,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { FMT_F16 = 0, FMT_BF16 = 1 };
+#define GDN_LOG2E 1.44269504088896340736f
+// f16 terms: alpha is scaled by 2^12 and the projected tile by 2^3 before they are split, so that the
+// lo terms of small weights / small features stay above the f16 subnormal floor (6e-8); the product is
+// unscaled by 2^-15 inside the epilogue constants.  |xlin'| must stay below 65504 / 8.
+#define GDN_F16_ALPHA_SCALE 4096.0f
+#define GDN_F16_X_SCALE 8.0f
 
 // ---- 16-bit term splitting ------------------------------------------------------------------------
 template <int FMT>
@@ -124,8 +130,10 @@ struct DCfg {
   static constexpr int THREADS = 64 * NT;
   static constexpr int AROW = KS * 32 + 16;            // bytes per target row of one plane (+16: rows
                                                        // land on distinct 16-B slots, ds_read_b128 conflict-free)
-  static constexpr int APLANE = 32 * AROW;
-  static constexpr int AWAVE = 2 * APLANE;             // hi + lo plane of a wave's 32 targets
+  static constexpr int AWAVE = 32 * AROW;              // ONE 16-bit plane of a wave's 32 targets: the hi and the
+                                                       // lo term of alpha take turns in it (scatter hi, its
+                                                       // products, scatter lo over the same positions, its
+                                                       // product), which halves the image: 2 workgroups per CU
   static constexpr int NPX = FMT == FMT_F16 ? 2 : 1;   // terms of the projected tile
   static constexpr int NTL = FMT == FMT_F16 ? 2 : 3;   // terms of lin.weight / a_i / a_j
   static constexpr int NTXIN = FMT == FMT_F16 ? 2 : 1; // terms of the x values (bf16 storage: exact)
@@ -136,7 +144,9 @@ struct DCfg {
   static constexpr int OFF_XS = OFF_XF + KS * DC * NPX * 1024;
   static constexpr int OFF_SI = OFF_XS + ROWS * XP * 4;
   static constexpr int OFF_SJ = OFF_SI + ROWS * 4;
-  static constexpr int LDS = OFF_SJ + ROWS * 4;
+  static constexpr int OFF_EC = OFF_SJ + ROWS * 4;     // epilogue column constants: 4 tables of 32 DC floats
+  static constexpr int OFF_CS = OFF_EC + 4 * 32 * DC * 4;   // C-in of the scalar tile: [c_i | c_j | zeros][ROWS]
+  static constexpr int LDS = OFF_CS + 3 * ROWS * 4;
 };
 
 struct DArgs {
@@ -163,8 +173,65 @@ __device__ __forceinline__ u32x4 lds_frag(const char* smem, int byte_off) {
   return *reinterpret_cast<const u32x4*>(smem + byte_off);
 }
 
+// Softmax of one target over the 2 x SL list slots of a lane pair (graph_layer.py:106-110 + PyG softmax),
+// in the log2 domain (s_i, s_j carry a factor log2 e; LeakyReLU commutes with a positive scale).  Returns
+// the weights split into two 16-bit terms, packed in slot pairs (and, WANT_ALPHA, the fp32 weights).
+template <int SL, int FMT, bool WANT_ALPHA>
+__device__ __forceinline__ void softmax_split(const char* smem, int si_off, const int (&sjoff)[SL],
+                                              unsigned (&ph)[SL / 2], unsigned (&pl)[SL / 2], float (&alpha)[SL]) {
+  using F = Fmt<FMT>;
+  const float sti = lds_f32(smem, si_off);
+  float e[SL];
+#pragma unroll
+  for (int q = 0; q < SL; ++q) e[q] = lds_f32(smem, sjoff[q]);    // all gathers in flight together
+  __builtin_amdgcn_sched_barrier(0);
+  float m = -3.0e38f;   // keeps pad targets (all slots = sentinel) finite
+#pragma unroll
+  for (int q = 0; q < SL; ++q) {
+    e[q] = leaky(sti + e[q]);
+    m = fmaxf(m, e[q]);
+  }
+  m = fmaxf(m, dpp_f<GDN_DPP_XOR1>(m));
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < SL; ++q) {
+    e[q] = __builtin_amdgcn_exp2f(e[q] - m);
+    sum += e[q];
+  }
+  sum += dpp_f<GDN_DPP_XOR1>(sum);
+  constexpr float ASC = FMT == FMT_F16 ? GDN_F16_ALPHA_SCALE : 1.f;   // inv = ASC / (sum + eps)
+  const float inv = __builtin_amdgcn_rcpf(fmaf(sum, 1.f / ASC, GDN_SOFTMAX_EPS / ASC));
+#pragma unroll
+  for (int q = 0; q < SL; q += 2) {
+    const float a0 = e[q] * inv, a1 = e[q + 1] * inv;
+    ph[q / 2] = F::pk(a0, a1);
+    pl[q / 2] = F::pk(F::res0(ph[q / 2], a0), F::res1(ph[q / 2], a1));
+    if constexpr (WANT_ALPHA) {
+      alpha[q] = a0 * (1.f / ASC);
+      alpha[q + 1] = a1 * (1.f / ASC);
+    }
+  }
+}
+
+template <int SL>
+__device__ __forceinline__ void scatter_terms(char* smem, const int (&scoff)[SL], const unsigned (&p)[SL / 2]) {
+#pragma unroll
+  for (int q = 0; q < SL; q += 2) {
+    *reinterpret_cast<uint16_t*>(smem + scoff[q]) = (uint16_t)p[q / 2];
+    *reinterpret_cast<uint16_t*>(smem + scoff[q + 1]) = (uint16_t)(p[q / 2] >> 16);
+  }
+}
+
+// clamped unconditional global load + select: the prologue's loads all issue back to back
+__device__ __forceinline__ float ld_or(const float* p, int idx, bool ok, float other = 0.f) {
+  const float v = p[ok ? idx : 0];
+  return ok ? v : other;
+}
+
 template <int NT, int DC, int WK, int SL, int FMT>
-__global__ __launch_bounds__(64 * NT) void gdn_dense_fused_kernel(const DArgs a) {
+// two workgroups per CU (2 waves per SIMD, <= 256 registers) where the constants fit; the long-list /
+// long-window variants take the whole register file (accumulator registers as spill space) at one
+__global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) void gdn_dense_fused_kernel(const DArgs a) {
   using C = DCfg<NT, DC, WK, SL, FMT>;
   using F = Fmt<FMT>;
   extern __shared__ uint4 smem_u4[];
@@ -177,19 +244,32 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_fused_kernel(const DArgs a)
   // ---------------------------------------------------------------- once per workgroup
   for (int t = lane; t < C::AWAVE / 16; t += 64)
     reinterpret_cast<uint4*>(smem + C::OFF_A + wv * C::AWAVE)[t] = make_uint4(0, 0, 0, 0);
-  float* xs = reinterpret_cast<float*>(smem + C::OFF_XS);
-  for (int t = tid; t < C::ROWS * C::XP; t += C::THREADS) xs[t] = 0.f;
+  {   // pad columns CW .. XP-1 of the x tile are never read; columns w .. CW-1 and rows >= n are stored as 0
+  }
+  // epilogue column constants [sh2 | out_w | sc1 | sh1'] (the last two only without the BatchNorm fold)
+  {
+    float* ec = reinterpret_cast<float*>(smem + C::OFF_EC);
+    for (int c = tid; c < d; c += C::THREADS) {
+      ec[c] = a.bn2[d + c];
+      ec[d + c] = a.out_w[c];
+      ec[2 * d + c] = a.bn1[c];
+      ec[3 * d + c] = fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]);
+    }
+  }
 
   // S: this lane's half of one target's neighbour list
   const int ti = 32 * wv + (lane >> 1);
   const int half = lane & 1;
   int sjoff[SL], scoff[SL];
+  {
+    const uint16_t* row = a.nbr + (size_t)min(ti, n - 1) * a.pitch + half * SL;
 #pragma unroll
-  for (int q = 0; q < SL; ++q) {
-    const int p = half * SL + q;
-    const int j = ti < n ? (int)a.nbr[ti * a.pitch + p] : n;
-    sjoff[q] = C::OFF_SJ + j * 4;
-    scoff[q] = C::OFF_A + wv * C::AWAVE + (lane >> 1) * C::AROW + pos_of_source(j) * 2;
+    for (int q = 0; q < SL; ++q) {
+      const int jj = (int)row[q];
+      const int j = ti < n ? jj : n;
+      sjoff[q] = C::OFF_SJ + j * 4;
+      scoff[q] = C::OFF_A + wv * C::AWAVE + (lane >> 1) * C::AROW + pos_of_source(j) * 2;
+    }
   }
   const int si_off = C::OFF_SI + ti * 4;
 
@@ -199,15 +279,15 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_fused_kernel(const DArgs a)
 #pragma unroll
   for (int cb = 0; cb < DC; ++cb) {
     const int c = cb * 32 + l32;
-    const float sc = FOLD ? a.bn1[c] : 1.f;
-    cin[cb] = FOLD ? fmaf(a.gnn_bias[c], sc, a.bn1[d + c]) : 0.f;
+    const float sc = FOLD ? a.bn1[c] * GDN_F16_X_SCALE : 1.f;
+    cin[cb] = FOLD ? fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]) * GDN_F16_X_SCALE : 0.f;
 #pragma unroll
     for (int wk = 0; wk < WK; ++wk) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = wk * 16 + 8 * h + j;
-        v[j] = k < w ? a.lin_w[c * w + k] * sc : 0.f;
+        v[j] = ld_or(a.lin_w, c * w + k, k < w) * sc;
       }
       split8<FMT, C::NTL>(v, bl[cb][wk]);
     }
@@ -218,63 +298,68 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_fused_kernel(const DArgs a)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = wk * 16 + 8 * h + j;   // a_i / a_j are stored zero padded to 64
-      v[j] = l32 < 2 ? a.node_terms[l32 * GDN_A_PITCH + k] : 0.f;
+      v[j] = ld_or(a.node_terms, l32 * GDN_A_PITCH + k, l32 < 2) * GDN_LOG2E;
     }
     split8<FMT, C::NTL>(v, bs[wk]);
   }
-  // C-in of the scalar tile: c_i / c_j of the row's sensor; row n (the list sentinel) gets s_j = -inf
-  float cs[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
-    float v = 0.f;
-    if (l32 < 2 && row < n) v = a.node_terms[2 * GDN_A_PITCH + l32 * n + row];
-    if (l32 == 1 && row == n) v = -INFINITY;
-    cs[r] = v;
+  // C-in of the scalar tile, kept in LDS (16 accumulator registers are initialised from it every window):
+  // c_i / c_j of the row's sensor (log2 domain); row n, the list sentinel, gets s_j = -inf; the lanes of
+  // the 30 unused columns read the zero row
+  {
+    float* ct = reinterpret_cast<float*>(smem + C::OFF_CS);
+    for (int t = tid; t < 3 * C::ROWS; t += C::THREADS) {
+      const int which = t / C::ROWS, row = t - which * C::ROWS;
+      float v = ld_or(a.node_terms, 2 * GDN_A_PITCH + which * n + row, which < 2 && row < n) * GDN_LOG2E;
+      if (which == 1 && row == n) v = -INFINITY;
+      ct[t] = v;
+    }
   }
+  const int cs_off = C::OFF_CS + (min(l32, 2) * C::ROWS + 32 * wv + 4 * h) * 4;   // + 32 (r >> 2): 4 rows
 
-  // E: per (column block, register) constants of this lane's target
+  // E: embedding x BatchNorm scale of this lane's target, per (column block, register)
   const int tgt = 32 * wv + l32;
-  float e2[DC][16], sh2v[DC][16], wov[DC][16];
-  float sc1v[FOLD ? 1 : DC][FOLD ? 1 : 16], sh1v[FOLD ? 1 : DC][FOLD ? 1 : 16];
+  float e2[DC][16];
 #pragma unroll
   for (int cb = 0; cb < DC; ++cb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      e2[cb][r] = tgt < n ? a.emb[tgt * d + c] * a.bn2[c] : 0.f;
-      sh2v[cb][r] = a.bn2[d + c];
-      wov[cb][r] = a.out_w[c];
-      if constexpr (!FOLD) {
-        sc1v[cb][r] = a.bn1[c];
-        sh1v[cb][r] = fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]);
-      }
+      e2[cb][r] = ld_or(a.emb, tgt * d + c, tgt < n) * a.bn2[c] *
+                  (FMT == FMT_F16 ? 1.f / (GDN_F16_ALPHA_SCALE * GDN_F16_X_SCALE) : 1.f);
     }
   const float out_b = a.out_b[0];
 
-  // x staging: flat element t of a window -> (row, column); offsets are window invariant
-  const int cnt = n * w;
-  int xg[C::XU], xl[C::XU];
+  // x staging: a thread owns column (tid % CW) of rows row0, row0 + RS, ...; global offsets are one VGPR
+  // plus a scalar step per row group (buffer loads: reads past the end of the input return 0), LDS
+  // offsets one VGPR plus an immediate.  Pad rows / columns are stored as 0 every window.
+  constexpr int CW = 16 * WK, RS = C::THREADS / CW;
+  static_assert(C::XU * RS == C::ROWS, "x staging covers the tile");
+  constexpr int ESZ = FMT == FMT_F16 ? 4 : 2;
+  const int xcol = tid & (CW - 1), xrow0 = tid / CW;
+  const int rstride = a.series_len > 0 ? a.series_len : w;
+  const int xvoff = (min(xrow0, n - 1) * rstride + min(xcol, w - 1)) * ESZ;
+  const int xstep = RS * rstride * ESZ;
+  const int xst_off = C::OFF_XS + (xrow0 * C::XP + xcol) * 4;
+  bool xok[C::XU];
 #pragma unroll
-  for (int u = 0; u < C::XU; ++u) {
-    const int t = tid + u * C::THREADS;
-    const int tc = min(t, cnt - 1);
-    const int row = tc / w, col = tc - row * w;
-    xg[u] = a.series_len > 0 ? row * a.series_len + col : tc;
-    xl[u] = t < cnt ? (row * C::XP + col) * 4 : -1;
-  }
-  const size_t win_stride = a.series_len > 0 ? 1 : (size_t)cnt;
+  for (int u = 0; u < C::XU; ++u) xok[u] = xcol < w && xrow0 + u * RS < n;
+  const size_t win_stride = a.series_len > 0 ? 1 : (size_t)n * w;
   const size_t x0 = a.series_len > 0 ? (size_t)a.series_first : 0;
+  const size_t x_total = (a.series_len > 0 ? (size_t)n * a.series_len : (size_t)a.batch * n * w) * ESZ;
   float xr[C::XU];
   auto load_window = [&](int bb) {
-    if constexpr (FMT == FMT_F16) {
-      const float* src = reinterpret_cast<const float*>(a.x) + x0 + (size_t)bb * win_stride;
+    const size_t first = (x0 + (size_t)bb * win_stride) * ESZ;          // wave uniform
+    const size_t rem = x_total - first;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.x)) + first, 0,
+        (int)(rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem), 0x00020000);
 #pragma unroll
-      for (int u = 0; u < C::XU; ++u) xr[u] = src[xg[u]];
-    } else {
-      const uint16_t* src = reinterpret_cast<const uint16_t*>(a.x) + x0 + (size_t)bb * win_stride;
-#pragma unroll
-      for (int u = 0; u < C::XU; ++u) xr[u] = __uint_as_float((unsigned)src[xg[u]] << 16);
+    for (int u = 0; u < C::XU; ++u) {
+      if constexpr (FMT == FMT_F16) {
+        xr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, xvoff, u * xstep, 0));
+      } else {
+        xr[u] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc, xvoff, u * xstep, 0) << 16);
+      }
     }
   };
   load_window(blockIdx.x);
@@ -282,114 +367,126 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_fused_kernel(const DArgs a)
 
   const int arow_off = C::OFF_A + wv * C::AWAVE + l32 * C::AROW + h * 16;   // alpha operand of this lane
   const int xrow_off = C::OFF_XS + ((32 * wv + l32) * C::XP + 8 * h) * 4;  // x operand of this lane
+  const int ec_off = C::OFF_EC + 16 * h;                                   // + 32 (r >> 2) + 128 cb: 4 columns
 
   for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
 #pragma unroll
     for (int u = 0; u < C::XU; ++u)
-      if (xl[u] >= 0) *reinterpret_cast<float*>(smem + C::OFF_XS + xl[u]) = xr[u];
+      *reinterpret_cast<float*>(smem + xst_off + u * (RS * C::XP * 4)) = xok[u] ? xr[u] : 0.f;
     __syncthreads();                                           // B1: x tile of window b visible
     load_window(min(b + (int)gridDim.x, a.batch - 1));         // lands under the math (last round: re-read)
 
     // ------------------------------------------------------------ P
-    f32x16 acc1[DC], accs;
+    {
+      f32x16 acc1[DC], accs;
 #pragma unroll
-    for (int cb = 0; cb < DC; ++cb)
+      for (int cb = 0; cb < DC; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[cb][r] = cin[cb];
+        for (int r = 0; r < 16; ++r) acc1[cb][r] = cin[cb];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accs[r] = cs[r];
-#pragma unroll
-    for (int wk = 0; wk < WK; ++wk) {
-      float v[8];
-      const float4 v0 = *reinterpret_cast<const float4*>(smem + xrow_off + wk * 64);
-      const float4 v1 = *reinterpret_cast<const float4*>(smem + xrow_off + wk * 64 + 16);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-      v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      u32x4 ax[C::NTXIN];
-      split8<FMT, C::NTXIN>(v, ax);
-#pragma unroll
-      for (int tx = 0; tx < C::NTXIN; ++tx)
-#pragma unroll
-        for (int tl = 0; tl < C::NTL; ++tl)
-          if (tx + tl < (C::NTXIN > C::NTL ? C::NTXIN : C::NTL)) {
-#pragma unroll
-            for (int cb = 0; cb < DC; ++cb) acc1[cb] = F::mfma(ax[tx], bl[cb][wk][tl], acc1[cb]);
-            accs = F::mfma(ax[tx], bs[wk][tl], accs);
-          }
-    }
-    // attention scalars: columns 0 / 1 of the scalar tile
-    if (l32 < 2) {
-      float* sdst = reinterpret_cast<float*>(smem + (l32 == 0 ? C::OFF_SI : C::OFF_SJ)) + 32 * wv + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sdst[(r & 3) + 8 * (r >> 2)] = accs[r];
-    }
-    // the projected tile as operand fragments of the aggregation product: k-steps 2wv, 2wv+1
-#pragma unroll
-    for (int cb = 0; cb < DC; ++cb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = acc1[cb][8 * s + j];
-        u32x4 xf[C::NPX];
-        split8<FMT, C::NPX>(v, xf);
-#pragma unroll
-        for (int t = 0; t < C::NPX; ++t)
-          *reinterpret_cast<u32x4*>(smem + C::OFF_XF + ((((2 * wv + s) * DC + cb) * C::NPX + t) << 10) + lane * 16) = xf[t];
+      for (int g = 0; g < 4; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(smem + cs_off + 32 * g);
+        accs[4 * g] = t.x; accs[4 * g + 1] = t.y; accs[4 * g + 2] = t.z; accs[4 * g + 3] = t.w;
       }
+#pragma unroll
+      for (int wk = 0; wk < WK; ++wk) {
+        float v[8];
+        const float4 v0 = *reinterpret_cast<const float4*>(smem + xrow_off + wk * 64);
+        const float4 v1 = *reinterpret_cast<const float4*>(smem + xrow_off + wk * 64 + 16);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        u32x4 ax[C::NTXIN];
+        split8<FMT, C::NTXIN>(v, ax);
+#pragma unroll
+        for (int tx = 0; tx < C::NTXIN; ++tx)
+#pragma unroll
+          for (int tl = 0; tl < C::NTL; ++tl)
+            if (tx + tl < (C::NTXIN > C::NTL ? C::NTXIN : C::NTL)) {
+#pragma unroll
+              for (int cb = 0; cb < DC; ++cb) acc1[cb] = F::mfma(ax[tx], bl[cb][wk][tl], acc1[cb]);
+              accs = F::mfma(ax[tx], bs[wk][tl], accs);
+            }
+      }
+      // attention scalars: columns 0 / 1 of the scalar tile
+      if (l32 < 2) {
+        float* sdst = reinterpret_cast<float*>(smem + (l32 == 0 ? C::OFF_SI : C::OFF_SJ)) + 32 * wv + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sdst[(r & 3) + 8 * (r >> 2)] = accs[r];
+      }
+      // the projected tile as operand fragments of the aggregation product: k-steps 2wv, 2wv+1
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = acc1[cb][8 * s + j];
+          u32x4 xf[C::NPX];
+          split8<FMT, C::NPX>(v, xf);
+#pragma unroll
+          for (int t = 0; t < C::NPX; ++t)
+            *reinterpret_cast<u32x4*>(smem + C::OFF_XF + ((((2 * wv + s) * DC + cb) * C::NPX + t) << 10) + lane * 16) = xf[t];
+        }
+    }
     __syncthreads();                                           // B2: tile fragments + scalars visible
 
     // ------------------------------------------------------------ S
+    // log2 domain: a_i, a_j, c_i, c_j carry a factor log2(e) (LeakyReLU commutes with a positive
+    // scale), so the weights are exp2(e - m) and v_exp_f32 needs no multiply in front of it
+    unsigned ph[SL / 2], pl[SL / 2];
     {
-      const float sti = lds_f32(smem, si_off);
-      float e[SL];
-      float m = -3.0e38f;   // keeps pad targets (all slots = sentinel) finite
-#pragma unroll
-      for (int q = 0; q < SL; ++q) {
-        e[q] = leaky(sti + lds_f32(smem, sjoff[q]));
-        m = fmaxf(m, e[q]);
-      }
-      m = fmaxf(m, dpp_f<GDN_DPP_XOR1>(m));
-      float sum = 0.f;
-#pragma unroll
-      for (int q = 0; q < SL; ++q) {
-        e[q] = __expf(e[q] - m);
-        sum += e[q];
-      }
-      sum += dpp_f<GDN_DPP_XOR1>(sum);
-      const float inv = __builtin_amdgcn_rcpf(sum + GDN_SOFTMAX_EPS);
-#pragma unroll
-      for (int q = 0; q < SL; q += 2) {
-        const float a0 = e[q] * inv, a1 = e[q + 1] * inv;
-        const unsigned ph = F::pk(a0, a1);
-        const unsigned pl = F::pk(F::res0(ph, a0), F::res1(ph, a1));
-        *reinterpret_cast<uint16_t*>(smem + scoff[q]) = (uint16_t)ph;
-        *reinterpret_cast<uint16_t*>(smem + scoff[q + 1]) = (uint16_t)(ph >> 16);
-        *reinterpret_cast<uint16_t*>(smem + scoff[q] + C::APLANE) = (uint16_t)pl;
-        *reinterpret_cast<uint16_t*>(smem + scoff[q + 1] + C::APLANE) = (uint16_t)(pl >> 16);
-      }
+      float unused[SL];
+      softmax_split<SL, FMT, false>(smem, si_off, sjoff, ph, pl, unused);
     }
-    // the image is wave private: LDS executes a wave's accesses in order, no barrier needed
-    __builtin_amdgcn_wave_barrier();
-
     // ------------------------------------------------------------ M
+    // The image is wave private and LDS executes one wave's accesses in order: scatter the hi term,
+    // read it as operands, scatter the lo term over the same positions, read again — no barrier.
+    // Operand reads run one k-step ahead of the products (two named fragment sets).
     f32x16 acc2[DC];
 #pragma unroll
     for (int cb = 0; cb < DC; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
+    constexpr int XF_KS = (DC * C::NPX) << 10;          // bytes of fragments per k-step
+    const int xf_lane = C::OFF_XF + lane * 16;
+    u32x4 fa[2], fx[2][DC][C::NPX];
+    auto fetch_hi = [&](int ks, int buf) {
+      fa[buf] = lds_frag(smem, arow_off + ks * 32);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int t = 0; t < C::NPX; ++t) fx[buf][cb][t] = lds_frag(smem, xf_lane + ks * XF_KS + ((cb * C::NPX + t) << 10));
+    };
+    auto fetch_lo = [&](int ks, int buf) {
+      fa[buf] = lds_frag(smem, arow_off + ks * 32);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb) fx[buf][cb][0] = lds_frag(smem, xf_lane + ks * XF_KS + ((cb * C::NPX) << 10));
+    };
+    scatter_terms<SL>(smem, scoff, ph);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_hi(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      const u32x4 ah = lds_frag(smem, arow_off + ks * 32);
-      const u32x4 al = lds_frag(smem, arow_off + ks * 32 + C::APLANE);
+      if (ks + 1 < C::KS) fetch_hi(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int cb = 0; cb < DC; ++cb) {
-        const int xo = C::OFF_XF + (((ks * DC + cb) * C::NPX) << 10) + lane * 16;
-        const u32x4 xh = lds_frag(smem, xo);
-        acc2[cb] = F::mfma(xh, ah, acc2[cb]);
-        if constexpr (C::NPX == 2) acc2[cb] = F::mfma(lds_frag(smem, xo + 1024), ah, acc2[cb]);
-        acc2[cb] = F::mfma(xh, al, acc2[cb]);
-      }
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int t = 0; t < C::NPX; ++t) acc2[cb] = F::mfma(fx[ks & 1][cb][t], fa[ks & 1], acc2[cb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    scatter_terms<SL>(smem, scoff, pl);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_lo(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) fetch_lo(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb) acc2[cb] = F::mfma(fx[ks & 1][cb][0], fa[ks & 1], acc2[cb]);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ------------------------------------------------------------ E  (models/GDN.py:77-79,175-184)
@@ -397,15 +494,396 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_fused_kernel(const DArgs a)
 #pragma unroll
     for (int cb = 0; cb < DC; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc2[cb][r];
-        if constexpr (!FOLD) v = fmaf(v, sc1v[cb][r], sh1v[cb][r]);
-        v = fmaxf(v, 0.f);
-        v = fmaxf(fmaf(v, e2[cb][r], sh2v[cb][r]), 0.f);
-        part = fmaf(v, wov[cb][r], part);
+      for (int g = 0; g < 4; ++g) {
+        const float4 sh2 = *reinterpret_cast<const float4*>(smem + ec_off + 128 * cb + 32 * g);
+        const float4 wo = *reinterpret_cast<const float4*>(smem + ec_off + 4 * d + 128 * cb + 32 * g);
+        const float sh2a[4] = {sh2.x, sh2.y, sh2.z, sh2.w}, woa[4] = {wo.x, wo.y, wo.z, wo.w};
+        float sc1a[4] = {1.f, 1.f, 1.f, 1.f}, sh1a[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!FOLD) {
+          const float4 t0 = *reinterpret_cast<const float4*>(smem + ec_off + 8 * d + 128 * cb + 32 * g);
+          const float4 t1 = *reinterpret_cast<const float4*>(smem + ec_off + 12 * d + 128 * cb + 32 * g);
+          sc1a[0] = t0.x; sc1a[1] = t0.y; sc1a[2] = t0.z; sc1a[3] = t0.w;
+          sh1a[0] = t1.x; sh1a[1] = t1.y; sh1a[2] = t1.z; sh1a[3] = t1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc2[cb][4 * g + i];
+          if constexpr (!FOLD) v = fmaf(v, sc1a[i], sh1a[i]);
+          v = fmaxf(v, 0.f);
+          v = fmaxf(fmaf(v, e2[cb][4 * g + i], sh2a[i]), 0.f);
+          part = fmaf(v, woa[i], part);
+        }
       }
     part += __shfl_xor(part, 32);
     if (h == 0 && tgt < n) a.out[(size_t)b * n + tgt] = part + out_b;
+  }
+}
+
+// ------------------------------------------------------------------ staged gather-aggregate (K8)
+// z[b] = alpha[b] . xlin[b] + bias for windows whose projected tile xlin[n, 64] and attention scalars
+// come from HBM (gdn_project_fwd): models/graph_layer.py:65-74,82-117.  Same softmax / scatter /
+// matrix-core product as the fused kernel; the tile is staged ROW-major in 16-bit terms (fp32 storage:
+// two f16 terms per value; bf16 storage: the stored value itself) and read back TRANSPOSED by
+// ds_read_b64_tr_b16 as the B operand (k = source sensor on the registers, column on the lane), so
+// Z = A . X comes out with the target in the registers and the column on the lane: every accumulator
+// register is one 128-byte row segment of z.
+//
+// Tile image: [ROWS][64] 16-bit, 128-byte rows, the two 64-byte halves of a row exchanged on rows with
+// bit 1 set: the four rows of one transposed read then cover all 64 banks (conflict-free).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int SL, int FMT>
+struct KCfg {
+  static constexpr int KS = 2 * NT;
+  static constexpr int ROWS = 32 * NT;
+  static constexpr int THREADS = 64 * NT;
+  static constexpr int AROW = KS * 32 + 16;
+  static constexpr int AWAVE = 32 * AROW;
+  static constexpr int NPX = FMT == FMT_F16 ? 2 : 1;
+  static constexpr int TPLANE = ROWS * 128;
+  static constexpr int OFF_A = 0;
+  static constexpr int OFF_T = NT * AWAVE;
+  static constexpr int OFF_SI = OFF_T + NPX * TPLANE;
+  static constexpr int OFF_SJ = OFF_SI + ROWS * 4;
+  static constexpr int LDS = OFF_SJ + ROWS * 4;
+  // tile staging: 16-byte pieces per row (fp32: 4 columns, bf16: 8 columns) and per thread
+  static constexpr int PPR = FMT == FMT_F16 ? 16 : 8;
+  static constexpr int RSTEP = THREADS / PPR;           // rows between a thread's pieces (multiple of 4)
+  static constexpr int TU = ROWS / RSTEP;               // pieces per thread: 8 (fp32) / 4 (bf16)
+};
+
+struct KArgs {
+  const void* xlin;        // [BN, 64] fp32 / bf16
+  const float* si;         // [BN]
+  const float* sj;
+  const uint16_t* nbr;     // [n, pitch]
+  const float* bias;       // [64]
+  int batch, n, pitch;
+  void* z;                 // [BN, 64] fp32 / bf16
+  float* alpha;            // [BN, pitch] or null
+};
+
+template <int NT, int SL, int FMT, bool WANT_ALPHA>
+__global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kernel(const KArgs a) {
+  using C = KCfg<NT, SL, FMT>;
+  using F = Fmt<FMT>;
+  constexpr int DC = 2;
+  extern __shared__ uint4 smem_u4[];
+  char* smem = reinterpret_cast<char*>(smem_u4);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int n = a.n;
+  constexpr int ESZ = FMT == FMT_F16 ? 4 : 2;
+
+  // ---------------------------------------------------------------- once per workgroup
+  for (int t = lane; t < C::AWAVE / 16; t += 64)
+    reinterpret_cast<uint4*>(smem + C::OFF_A + wv * C::AWAVE)[t] = make_uint4(0, 0, 0, 0);
+  const int ti = 32 * wv + (lane >> 1);
+  const int half = lane & 1;
+  int sjoff[SL], scoff[SL];
+  {
+    const uint16_t* row = a.nbr + (size_t)min(ti, n - 1) * a.pitch + half * SL;
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+      const int jj = (int)row[q];
+      const int j = ti < n ? jj : n;
+      sjoff[q] = C::OFF_SJ + j * 4;
+      scoff[q] = C::OFF_A + wv * C::AWAVE + (lane >> 1) * C::AROW + pos_of_source(j) * 2;
+    }
+  }
+  const int si_off = C::OFF_SI + ti * 4;
+  float bias[DC];
+#pragma unroll
+  for (int cb = 0; cb < DC; ++cb)
+    bias[cb] = a.bias[cb * 32 + l32] * (FMT == FMT_F16 ? GDN_F16_ALPHA_SCALE : 1.f);
+
+  // tile staging: piece u of this thread = row prow0 + u RSTEP, 16-byte piece ppc of the row
+  const int ppc = tid % C::PPR, prow0 = tid / C::PPR;
+  const int t_st = C::OFF_T + prow0 * 128 +
+                   (FMT == FMT_F16 ? (((ppc >> 3) ^ ((prow0 >> 1) & 1)) * 64 + (ppc & 7) * 8)
+                                   : (((ppc >> 2) ^ ((prow0 >> 1) & 1)) * 64 + (ppc & 3) * 16));
+  const int t_voff = (prow0 * 64 + ppc * (16 / ESZ)) * ESZ;       // bytes from the window's first row
+  bool tok[C::TU];
+#pragma unroll
+  for (int u = 0; u < C::TU; ++u) tok[u] = prow0 + u * C::RSTEP < n;
+  const size_t t_total = (size_t)a.batch * n * 64 * ESZ;
+  uint4 pre[C::TU];
+  float psi, psj;
+  const int sn = min(tid, n - 1);
+  auto load_window = [&](int bb) {
+    const size_t first = (size_t)bb * n * 64 * ESZ;
+    const size_t rem = t_total - first;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.xlin)) + first, 0,
+        (int)(rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < C::TU; ++u) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t_voff, u * (C::RSTEP * 64 * ESZ), 0);
+      pre[u] = __builtin_bit_cast(uint4, v);
+    }
+    psi = a.si[(size_t)bb * n + sn];
+    psj = a.sj[(size_t)bb * n + sn];
+  };
+  // rows >= n of the tile (the list sentinel n and the pad rows) stay zero: they are never stored again
+  for (int t = tid; t < C::NPX * C::TPLANE / 16; t += C::THREADS)
+    reinterpret_cast<uint4*>(smem + C::OFF_T)[t] = make_uint4(0, 0, 0, 0);
+  if (tid == 0) *reinterpret_cast<float*>(smem + C::OFF_SJ + n * 4) = -INFINITY;
+  load_window(blockIdx.x);
+  __syncthreads();
+
+  const int arow_off = C::OFF_A + wv * C::AWAVE + l32 * C::AROW + h * 16;   // alpha operand (A) of this lane
+  // transposed reads: lane 4q+p of a 16-lane group addresses row q, columns 4p .. 4p+3 of its block
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tsw = (tq >> 1) & 1;
+  const int tr_base = C::OFF_T + (4 * h + tq) * 128 + 32 * (g & 1) + 8 * tp;   // + (cb ^ tsw) 64 + ks 2048 + rd 1024
+  using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+
+  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+    // ---- tile of window b -> LDS (16-bit terms), scalars -> LDS (log2 domain)
+#pragma unroll
+    for (int u = 0; u < C::TU; ++u) {
+      if (!tok[u]) continue;        // pad rows stay zero (the loads past row n read the next window)
+      char* dst = smem + t_st + u * (C::RSTEP * 128);
+      if constexpr (FMT == FMT_F16) {
+        const float v0 = __uint_as_float(pre[u].x), v1 = __uint_as_float(pre[u].y);
+        const float v2 = __uint_as_float(pre[u].z), v3 = __uint_as_float(pre[u].w);
+        const unsigned h0 = F::pk(v0, v1), h1 = F::pk(v2, v3);
+        const unsigned l0 = F::pk(F::res0(h0, v0), F::res1(h0, v1)), l1 = F::pk(F::res0(h1, v2), F::res1(h1, v3));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + C::TPLANE) = make_uint2(l0, l1);
+      } else {
+        *reinterpret_cast<uint4*>(dst) = pre[u];
+      }
+    }
+    if (tid < n) {
+      *reinterpret_cast<float*>(smem + C::OFF_SI + tid * 4) = psi * GDN_LOG2E;
+      *reinterpret_cast<float*>(smem + C::OFF_SJ + tid * 4) = psj * GDN_LOG2E;
+    }
+    __syncthreads();                                           // B1
+    load_window(min(b + (int)gridDim.x, a.batch - 1));
+
+    // ---- S
+    unsigned ph[SL / 2], pl[SL / 2];
+    {
+      float al[SL];
+      softmax_split<SL, FMT, WANT_ALPHA>(smem, si_off, sjoff, ph, pl, al);
+      if constexpr (WANT_ALPHA) {
+        if (ti < n) {
+          float4* dst = reinterpret_cast<float4*>(a.alpha + ((size_t)b * n + ti) * a.pitch + half * SL);
+#pragma unroll
+          for (int q = 0; q < SL; q += 4) dst[q / 4] = make_float4(al[q], al[q + 1], al[q + 2], al[q + 3]);
+        }
+      }
+    }
+    // ---- M: Z = A . X, target on the registers, column on the lane; C-in = bias
+    f32x16 acc[DC];
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][r] = bias[cb];   // (bias carries the alpha scale)
+    u32x4 fa[2], fx[2][DC][C::NPX];
+    auto fetch = [&](int ks, int buf, int nterms) {
+      fa[buf] = lds_frag(smem, arow_off + ks * 32);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int t = 0; t < C::NPX; ++t) {
+          if (t >= nterms) continue;
+          const char* p0 = smem + tr_base + t * C::TPLANE + ks * 2048;
+          const int co = cb == 0 ? tsw * 64 : (tsw ^ 1) * 64;
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + co));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + co + 1024));
+          const uint2 u0 = __builtin_bit_cast(uint2, r0), u1 = __builtin_bit_cast(uint2, r1);
+          fx[buf][cb][t] = u32x4{u0.x, u0.y, u1.x, u1.y};
+        }
+    };
+    scatter_terms<SL>(smem, scoff, ph);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(0, 0, C::NPX);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) fetch(ks + 1, (ks + 1) & 1, C::NPX);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int t = 0; t < C::NPX; ++t) acc[cb] = F::mfma(fa[ks & 1], fx[ks & 1][cb][t], acc[cb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    scatter_terms<SL>(smem, scoff, pl);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) fetch(ks + 1, (ks + 1) & 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb) acc[cb] = F::mfma(fa[ks & 1], fx[ks & 1][cb][0], acc[cb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- z rows: register r = target 32wv + (r&3) + 8(r>>2) + 4h, lane = column
+    constexpr float UNSCALE = FMT == FMT_F16 ? 1.f / GDN_F16_ALPHA_SCALE : 1.f;
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[cb][r] * UNSCALE;
+        if constexpr (FMT == FMT_F16) {
+          if (row < n) reinterpret_cast<float*>(a.z)[((size_t)b * n + row) * 64 + cb * 32 + l32] = v;
+        } else {
+          const float nb = dpp_f<GDN_DPP_XOR1>(v);            // the odd neighbour's column
+          if (row < n && (lane & 1) == 0)
+            reinterpret_cast<unsigned*>(a.z)[(((size_t)b * n + row) * 64 + cb * 32 + l32) >> 1] = F::pk(v, nb);
+        }
+      }
+    __syncthreads();                                           // B2: tile and scalars free
+  }
+}
+
+// ------------------------------------------------------------------ staged projection
+// xlin[b] = x[b] . lin^T (models/graph_layer.py:56) and the attention scalars s_i, s_j of every sensor
+// (graph_layer.py:94-104 folded: s = x_row . a + c[sensor]) on the 16-bit matrix cores: the P phase of
+// the fused kernel without the BatchNorm fold, results written to HBM.  fp32 storage: x and lin are
+// split into two f16 terms (three products, fp32-grade); bf16 storage: x is exact, lin three bf16 terms,
+// xlin rounded to bf16 once.
+struct PArgs {
+  const void* x;            // [B, n, w] fp32 / bf16
+  const float* lin_w;       // [64, w]
+  const float* node_terms;
+  int batch, n, w;
+  void* xlin;               // [BN, 64] fp32 / bf16
+  float* si;
+  float* sj;
+};
+
+template <int NT, int WK, int FMT>
+__global__ __launch_bounds__(64 * NT) void gdn_dense_project_kernel(const PArgs a) {
+  using F = Fmt<FMT>;
+  constexpr int DC = 2, ROWS = 32 * NT, THREADS = 64 * NT, XP = 16 * WK + 4, XU = 8 * WK;
+  constexpr int NTL = FMT == FMT_F16 ? 2 : 3, NTXIN = FMT == FMT_F16 ? 2 : 1;
+  constexpr int OFF_XS = 0, OFF_CS = ROWS * XP * 4, LDS = OFF_CS + 3 * ROWS * 4;
+  __shared__ uint4 smem_u4[LDS / 16 + 1];
+  char* smem = reinterpret_cast<char*>(smem_u4);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int n = a.n, w = a.w;
+
+  u32x4 bl[DC][WK][NTL], bs[WK][NTL];
+#pragma unroll
+  for (int wk = 0; wk < WK; ++wk) {
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = wk * 16 + 8 * h + j;
+        v[j] = ld_or(a.lin_w, (cb * 32 + l32) * w + k, k < w);
+      }
+      split8<FMT, NTL>(v, bl[cb][wk]);
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ld_or(a.node_terms, l32 * GDN_A_PITCH + wk * 16 + 8 * h + j, l32 < 2);
+    split8<FMT, NTL>(v, bs[wk]);
+  }
+  {
+    float* ct = reinterpret_cast<float*>(smem + OFF_CS);
+    for (int t = tid; t < 3 * ROWS; t += THREADS) {
+      const int which = t / ROWS, row = t - which * ROWS;
+      ct[t] = ld_or(a.node_terms, 2 * GDN_A_PITCH + which * n + row, which < 2 && row < n);
+    }
+  }
+  const int cs_off = OFF_CS + (min(l32, 2) * ROWS + 32 * wv + 4 * h) * 4;
+
+  constexpr int CW = 16 * WK, RS = THREADS / CW;
+  constexpr int ESZ = FMT == FMT_F16 ? 4 : 2;
+  const int xcol = tid & (CW - 1), xrow0 = tid / CW;
+  const int xvoff = (min(xrow0, n - 1) * w + min(xcol, w - 1)) * ESZ;
+  const int xstep = RS * w * ESZ;
+  const int xst_off = OFF_XS + (xrow0 * XP + xcol) * 4;
+  bool xok[XU];
+#pragma unroll
+  for (int u = 0; u < XU; ++u) xok[u] = xcol < w && xrow0 + u * RS < n;
+  const size_t x_total = (size_t)a.batch * n * w * ESZ;
+  float xr[XU];
+  auto load_window = [&](int bb) {
+    const size_t first = (size_t)bb * n * w * ESZ;
+    const size_t rem = x_total - first;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.x)) + first, 0,
+        (int)(rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      if constexpr (FMT == FMT_F16) {
+        xr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, xvoff, u * xstep, 0));
+      } else {
+        xr[u] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc, xvoff, u * xstep, 0) << 16);
+      }
+    }
+  };
+  load_window(blockIdx.x);
+  __syncthreads();
+  const int xrow_off = OFF_XS + ((32 * wv + l32) * XP + 8 * h) * 4;
+
+  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u)
+      *reinterpret_cast<float*>(smem + xst_off + u * (RS * XP * 4)) = xok[u] ? xr[u] : 0.f;
+    __syncthreads();
+    load_window(min(b + (int)gridDim.x, a.batch - 1));
+    f32x16 acc1[DC], accs;
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[cb][r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + cs_off + 32 * g);
+      accs[4 * g] = t.x; accs[4 * g + 1] = t.y; accs[4 * g + 2] = t.z; accs[4 * g + 3] = t.w;
+    }
+#pragma unroll
+    for (int wk = 0; wk < WK; ++wk) {
+      float v[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(smem + xrow_off + wk * 64);
+      const float4 v1 = *reinterpret_cast<const float4*>(smem + xrow_off + wk * 64 + 16);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+      v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      u32x4 ax[NTXIN];
+      split8<FMT, NTXIN>(v, ax);
+#pragma unroll
+      for (int tx = 0; tx < NTXIN; ++tx)
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl)
+          if (tx + tl < (NTXIN > NTL ? NTXIN : NTL)) {
+#pragma unroll
+            for (int cb = 0; cb < DC; ++cb) acc1[cb] = F::mfma(ax[tx], bl[cb][wk][tl], acc1[cb]);
+            accs = F::mfma(ax[tx], bs[wk][tl], accs);
+          }
+    }
+    __syncthreads();   // x tile free for the next window
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < n) {
+        const size_t grow = (size_t)b * n + row;
+        if (l32 == 0) a.si[grow] = accs[r];
+        if (l32 == 1) a.sj[grow] = accs[r];
+      }
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb) {
+        const float v = acc1[cb][r];
+        if constexpr (FMT == FMT_F16) {
+          if (row < n) reinterpret_cast<float*>(a.xlin)[((size_t)b * n + row) * 64 + cb * 32 + l32] = v;
+        } else {
+          const float nb = dpp_f<GDN_DPP_XOR1>(v);
+          if (row < n && (lane & 1) == 0)
+            reinterpret_cast<unsigned*>(a.xlin)[(((size_t)b * n + row) * 64 + cb * 32 + l32) >> 1] = F::pk(v, nb);
+        }
+      }
+    }
   }
 }
 
@@ -490,7 +968,72 @@ int select_nt(const DArgs& a, hipStream_t st) {
   return GDN_ERR_UNSUPPORTED;
 }
 
+template <int NT, int SL, int FMT, bool WANT_ALPHA>
+int launch_attn(const KArgs& a, hipStream_t stream) {
+  using C = KCfg<NT, SL, FMT>;
+  static_assert(C::LDS <= 160 * 1024, "LDS plan exceeds one CU");
+  auto kern = gdn_dense_attn_kernel<NT, SL, FMT, WANT_ALPHA>;
+  const int occ = blocks_per_cu(reinterpret_cast<const void*>(kern), C::THREADS, C::LDS);
+  const int grid = max(1, min(a.batch, cu_count() * occ));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
+  return gdn_launch_status();
+}
+
+template <int NT, int FMT, bool WANT_ALPHA>
+int attn_select_sl(const KArgs& a, hipStream_t st) {
+  switch (a.pitch) {
+    case 16: return launch_attn<NT, 8, FMT, WANT_ALPHA>(a, st);
+    case 32: return launch_attn<NT, 16, FMT, WANT_ALPHA>(a, st);
+    case 48: return launch_attn<NT, 24, FMT, WANT_ALPHA>(a, st);
+    case 64: return launch_attn<NT, 32, FMT, WANT_ALPHA>(a, st);
+  }
+  return GDN_ERR_UNSUPPORTED;
+}
+
+template <int FMT, bool WANT_ALPHA>
+int attn_select_nt(const KArgs& a, hipStream_t st) {
+  switch ((a.n + 1 + 31) / 32) {
+    case 1: return attn_select_sl<1, FMT, WANT_ALPHA>(a, st);
+    case 2: return attn_select_sl<2, FMT, WANT_ALPHA>(a, st);
+    case 3: return attn_select_sl<3, FMT, WANT_ALPHA>(a, st);
+    case 4: return attn_select_sl<4, FMT, WANT_ALPHA>(a, st);
+  }
+  return GDN_ERR_UNSUPPORTED;
+}
+
 }  // namespace
+
+template <int NT, int FMT>
+int launch_project(const PArgs& a, hipStream_t stream) {
+  const int grid = max(1, min(a.batch, cu_count() * 8));
+  if (a.w <= 16) hipLaunchKernelGGL((gdn_dense_project_kernel<NT, 1, FMT>), dim3(grid), dim3(64 * NT), 0, stream, a);
+  else hipLaunchKernelGGL((gdn_dense_project_kernel<NT, 2, FMT>), dim3(grid), dim3(64 * NT), 0, stream, a);
+  return gdn_launch_status();
+}
+
+int gdn_dense_project(const void* x, int is_bf16, const float* lin_w, const float* node_terms, int batch, int n,
+                      int w, int d, void* xlin, float* s_i, float* s_j, hipStream_t stream) {
+  if (!gdn_dense_supported(n, w, d, 1)) return GDN_ERR_UNSUPPORTED;
+  PArgs a = {x, lin_w, node_terms, batch, n, w, xlin, s_i, s_j};
+  switch ((n + 1 + 31) / 32) {
+    case 1: return is_bf16 ? launch_project<1, FMT_BF16>(a, stream) : launch_project<1, FMT_F16>(a, stream);
+    case 2: return is_bf16 ? launch_project<2, FMT_BF16>(a, stream) : launch_project<2, FMT_F16>(a, stream);
+    case 3: return is_bf16 ? launch_project<3, FMT_BF16>(a, stream) : launch_project<3, FMT_F16>(a, stream);
+    case 4: return is_bf16 ? launch_project<4, FMT_BF16>(a, stream) : launch_project<4, FMT_F16>(a, stream);
+  }
+  return GDN_ERR_UNSUPPORTED;
+}
+
+int gdn_dense_attn_aggregate(const void* xlin, int is_bf16, const float* s_i, const float* s_j, const uint16_t* nbr,
+                             const float* bias, int batch, int n, int d, int k, void* z, float* alpha,
+                             hipStream_t stream) {
+  if (!gdn_dense_supported(n, 1, d, k)) return GDN_ERR_UNSUPPORTED;
+  KArgs a = {};
+  a.xlin = xlin; a.si = s_i; a.sj = s_j; a.nbr = nbr; a.bias = bias;
+  a.batch = batch; a.n = n; a.pitch = gdn_nbr_pitch(k); a.z = z; a.alpha = alpha;
+  if (is_bf16) return alpha ? attn_select_nt<FMT_BF16, true>(a, stream) : attn_select_nt<FMT_BF16, false>(a, stream);
+  return alpha ? attn_select_nt<FMT_F16, true>(a, stream) : attn_select_nt<FMT_F16, false>(a, stream);
+}
 
 // Shapes the dense matrix-core path takes: n <= 127, d = 64, w <= 32, list pitch <= 64 (k <= 63).
 bool gdn_dense_supported(int n, int w, int d, int k) {

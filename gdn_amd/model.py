@@ -294,14 +294,17 @@ class GDN(nn.Module):
         b = x.shape[0]
         if x.shape[1] != n or x.shape[2] != w:
             raise ValueError(f"expected data of shape [B, {n}, {w}], got {tuple(x.shape)}")
-        _lib.call("gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(),
+        name = "gdn_forward_fused_bf16" if x.dtype == torch.bfloat16 else "gdn_forward_fused"
+        _lib.call(name, x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(),
                   torch.cuda.current_stream().cuda_stream)
         return out
 
     # ------------------------------------------------------------------ forward
     def forward(self, data, org_edge_index=None):
         x = data.detach()                                                   # GDN.py:124
-        if x.dtype != torch.float32:
+        # bfloat16 windows select bf16 STORAGE of x / xlin / z (eval only; fp32 arithmetic, fp32 output)
+        bf16 = x.dtype == torch.bfloat16 and not self.training
+        if x.dtype != torch.float32 and not bf16:
             x = x.float()
         x = x.contiguous()
         batch, node_num, _ = x.shape
@@ -382,9 +385,9 @@ class GDN(nn.Module):
             raise RuntimeError("forward_into is the eval / out_layer_num == 1 fast path")
         c = self._constants()
         self.learned_graph = c.graph.topk
-        if data.dtype != torch.float32 or not data.is_contiguous():
-            data = data.float().contiguous()
-        return self._launch_fused(data, c, out)
+        if data.dtype not in (torch.float32, torch.bfloat16):
+            data = data.float()
+        return self._launch_fused(data.contiguous(), c, out)
 
     def forward_series(self, series, first: int, batch: int, out=None):
         """Eval forward of `batch` consecutive stride-1 windows taken directly from the raw series

@@ -95,40 +95,54 @@ def bn_fold(bn: torch.nn.BatchNorm1d) -> torch.Tensor:
     return out
 
 
+def _storage(t: torch.Tensor, name: str) -> str:
+    """"" for fp32 tensors, "_bf16" for bfloat16 ones: the suffix of the C entry point (bf16 STORAGE of
+    x / xlin / z, fp32 arithmetic — include/gdn_hip.h)."""
+    if t.dtype == torch.bfloat16:
+        return "_bf16"
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32 or bfloat16, got {t.dtype}")
+    return ""
+
+
 def project_fwd(x, lin_w, terms):
-    """x[B,n,w] -> xlin[B*n,d], s_i[B*n], s_j[B*n]  (models/graph_layer.py:56 + logit scalars)."""
-    x = _chk(x, name="x")
+    """x[B,n,w] -> xlin[B*n,d], s_i[B*n], s_j[B*n]  (models/graph_layer.py:56 + logit scalars).
+    bfloat16 x gives bfloat16 xlin (bf16 storage)."""
+    sfx = _storage(x, "x")
+    x = _chk(x, x.dtype, name="x")
     lin_w = _chk(lin_w.detach(), name="lin.weight")
     b, n, w = x.shape
     d = lin_w.shape[0]
-    xlin = torch.empty((b * n, d), dtype=torch.float32, device=x.device)
+    xlin = torch.empty((b * n, d), dtype=x.dtype, device=x.device)
     s_i = torch.empty((b * n,), dtype=torch.float32, device=x.device)
     s_j = torch.empty_like(s_i)
-    _lib.call("gdn_project_fwd", _ptr(x), _ptr(lin_w), _ptr(terms), b, n, w, d,
+    _lib.call("gdn_project_fwd" + sfx, _ptr(x), _ptr(lin_w), _ptr(terms), b, n, w, d,
               _ptr(xlin), _ptr(s_i), _ptr(s_j), _stream())
     return xlin, s_i, s_j
 
 
 def attn_aggregate_fwd(xlin, s_i, s_j, graph: SensorGraph, bias, batch: int, want_alpha: bool):
     """models/graph_layer.py:65-74,82-117 -> z[B*n,d] (+ dense alpha[B*n,pitch])."""
-    xlin = _chk(xlin, name="xlin")
+    sfx = _storage(xlin, "xlin")
+    xlin = _chk(xlin, xlin.dtype, name="xlin")
     bn, d = xlin.shape
     n = bn // batch
     z = torch.empty_like(xlin)
     alpha = torch.empty((bn, graph.pitch), dtype=torch.float32, device=xlin.device) if want_alpha else None
-    _lib.call("gdn_attn_aggregate_fwd", _ptr(xlin), _ptr(_chk(s_i)), _ptr(_chk(s_j)), _ptr(graph.nbr),
+    _lib.call("gdn_attn_aggregate_fwd" + sfx, _ptr(xlin), _ptr(_chk(s_i)), _ptr(_chk(s_j)), _ptr(graph.nbr),
               _ptr(graph.deg), _ptr(_chk(bias.detach())), batch, n, d, graph.k, _ptr(z), _ptr(alpha), _stream())
     return z, alpha
 
 
 def head_fwd(z, emb, bn1_affine, bn2_affine, out_w, out_b, batch: int, want_h2: bool = False):
     """Eval head: models/GDN.py:77-79,175-184 with out_layer_num == 1."""
-    z = _chk(z, name="z")
+    sfx = _storage(z, "z")
+    z = _chk(z, z.dtype, name="z")
     bn, d = z.shape
     n = bn // batch
     out = torch.empty((batch, n), dtype=torch.float32, device=z.device)
-    h2 = torch.empty_like(z) if want_h2 else None
-    _lib.call("gdn_head_fwd", _ptr(z), _ptr(_chk(emb.detach())), _ptr(bn1_affine), _ptr(bn2_affine),
+    h2 = torch.empty((bn, d), dtype=torch.float32, device=z.device) if want_h2 else None
+    _lib.call("gdn_head_fwd" + sfx, _ptr(z), _ptr(_chk(emb.detach())), _ptr(bn1_affine), _ptr(bn2_affine),
               _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
               batch, n, d, _ptr(out), _ptr(h2), _stream())
     return out, h2
@@ -197,14 +211,16 @@ def head_train_bwd(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, mask, stats
 
 def forward_fused(x, lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
                   out: torch.Tensor | None = None):
-    """One launch from x[B,n,w] to out[B,n]: models/GDN.py:122-187 under model.eval()."""
-    x = _chk(x, name="x")
+    """One launch from x[B,n,w] to out[B,n]: models/GDN.py:122-187 under model.eval().
+    bfloat16 x selects the bf16-storage kernel."""
+    sfx = _storage(x, "x")
+    x = _chk(x, x.dtype, name="x")
     b, n, w = x.shape
     lin_w = _chk(lin_w.detach(), name="lin.weight")
     d = lin_w.shape[0]
     if out is None:
         out = torch.empty((b, n), dtype=torch.float32, device=x.device)
-    _lib.call("gdn_forward_fused", _ptr(x), _ptr(lin_w), _ptr(terms), _ptr(graph.nbr), _ptr(graph.deg),
+    _lib.call("gdn_forward_fused" + sfx, _ptr(x), _ptr(lin_w), _ptr(terms), _ptr(graph.nbr), _ptr(graph.deg),
               _ptr(_chk(gnn_bias.detach())), _ptr(_chk(emb.detach())), _ptr(bn1_affine), _ptr(bn2_affine),
               _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
               b, n, w, d, graph.k, _ptr(out), _stream())

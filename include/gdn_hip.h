@@ -43,7 +43,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 9
+#define GDN_ABI_VERSION 10
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -106,7 +106,7 @@ int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const float* s_j
  * dropout = identity (:182), OutLayer with out_layer_num == 1 (:27-56) = Linear(d->1).
  * bn1_affine / bn2_affine come from gdn_bn_fold.  z[BN,d] -> out[BN].
  * h2 (optional, NULL to skip) receives the [BN,d] input of the OutLayer (needed when
- * out_layer_num > 1, whose MLP then runs through gdn_mlp_*).                            */
+ * out_layer_num > 1: the MLP then runs in gdn_mlp_fwd).                                  */
 int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
                  const float* bn2_affine, const float* out_w, const float* out_b,
                  int batch, int n, int d, float* out, float* h2, void* stream);
@@ -175,6 +175,36 @@ int gdn_forward_fused_series(const float* series, int series_len, int first, con
                              const float* gnn_bias, const float* emb, const float* bn1_affine,
                              const float* bn2_affine, const float* out_w, const float* out_b,
                              int batch, int n, int w, int d, int k, float* out, void* stream);
+
+/* ---- bf16 STORAGE variants (BASELINE.json configs[2] / configs[4]) --------------------
+ * Same arithmetic as the four forward entry points above with the windowed inputs x, the
+ * projected features xlin and the aggregate z held in bfloat16 IN HBM (uint16_t = the raw
+ * bf16 bit pattern, round-to-nearest-even where a value is stored); attention scalars,
+ * logits, softmax, every accumulation, BatchNorm and the outputs stay fp32
+ * (models/graph_layer.py:56,87-117 with 2-byte features).  Semantics, exactly:
+ *   x     is given in bf16 (exact);
+ *   xlin  = bf16( x . lin^T accumulated in fp32 )            [stored / LDS resident];
+ *   s_i, s_j from the UNROUNDED projection (x_row . a + c, fp32);
+ *   z     = sum_j alpha_ij xlin_j + bias in fp32; gdn_attn_aggregate_fwd_bf16 stores bf16(z),
+ *           gdn_forward_fused_bf16 keeps z on chip in fp32;
+ *   head  as gdn_head_fwd.
+ * Matrix-core path only: n <= 127, d = 64, w <= 32, k <= 63; other shapes return
+ * GDN_ERR_UNSUPPORTED.                                                                   */
+int gdn_project_fwd_bf16(const uint16_t* x, const float* lin_w, const float* node_terms,
+                         int batch, int n, int w, int d,
+                         uint16_t* xlin, float* s_i, float* s_j, void* stream);
+int gdn_attn_aggregate_fwd_bf16(const uint16_t* xlin, const float* s_i, const float* s_j,
+                                const uint16_t* nbr, const int32_t* deg, const float* bias,
+                                int batch, int n, int d, int k,
+                                uint16_t* z, float* alpha, void* stream);
+int gdn_head_fwd_bf16(const uint16_t* z, const float* emb, const float* bn1_affine,
+                      const float* bn2_affine, const float* out_w, const float* out_b,
+                      int batch, int n, int d, float* out, float* h2, void* stream);
+int gdn_forward_fused_bf16(const uint16_t* x, const float* lin_w, const float* node_terms,
+                           const uint16_t* nbr, const int32_t* deg, const float* gnn_bias,
+                           const float* emb, const float* bn1_affine, const float* bn2_affine,
+                           const float* out_w, const float* out_b,
+                           int batch, int n, int w, int d, int k, float* out, void* stream);
 
 /* ---- backward (training) -------------------------------------------------------------
  * Gradients of gdn_attn_aggregate_fwd and gdn_project_fwd; the autograd graph of

@@ -63,13 +63,25 @@ def strip_and_append_self_loops(edge_index: torch.Tensor, num_nodes: int) -> tor
 
 
 # ------------------------------------------------------------------ graph layer
+def round_bf16(t: torch.Tensor) -> torch.Tensor:
+    """Round to the nearest bfloat16 (ties to even) and return in the input dtype: what storing a
+    tensor in bf16 does to its values."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
 def graph_layer(p: dict, prefix: str, x: torch.Tensor, edge_index: torch.Tensor,
-                emb_rep: torch.Tensor):
+                emb_rep: torch.Tensor, storage: str = "fp32"):
     """models/graph_layer.py:53-117 with heads=1, concat=False, dropout=0
-    (hard-wired by models/GDN.py:65).  Returns (out, edge_index', alpha, xlin)."""
+    (hard-wired by models/GDN.py:65).  Returns (out, edge_index', alpha, xlin).
+
+    storage="bf16" (BASELINE configs[2]/[4]: bf16 storage, fp32 logits / softmax / accumulate): the
+    projected features are ROUNDED TO bf16 WHERE THEY ARE STORED, i.e. as the rows the messages gather
+    (x_j * alpha, :117); the attention logits (:94-104) are computed in fp32 from the unrounded
+    projection, as the HIP kernels compute them from x directly.  Returned xlin = the stored one."""
     lin_w = p[prefix + "lin.weight"]                      # [D, W]
     d = lin_w.shape[0]
     xlin = F.linear(x, lin_w)                             # :56
+    xlin_msg = round_bf16(xlin) if storage == "bf16" else xlin
     ei = strip_and_append_self_loops(edge_index, xlin.shape[0])  # :61-63
     src, tgt = ei[0], ei[1]
     # PyG propagate: _j <- edge_index[0], _i <- edge_index[1]
@@ -91,11 +103,13 @@ def graph_layer(p: dict, prefix: str, x: torch.Tensor, edge_index: torch.Tensor,
     e = (logit - gmax[tgt]).exp()
     gsum = torch.zeros((n, 1, 1), dtype=logit.dtype).scatter_add_(0, idx, e)
     alpha = e / (gsum[tgt] + SOFTMAX_EPS)
+    if storage == "bf16":
+        x_j = xlin_msg.index_select(0, src).view(-1, 1, d)
     msg = x_j * alpha.view(-1, 1, 1)                      # :117 (dropout p=0 at :115 is identity)
     agg = torch.zeros((n, 1, d), dtype=msg.dtype).scatter_add_(
         0, tgt.view(-1, 1, 1).expand_as(msg), msg)        # PyG aggregate, aggr='add'
     out = agg.mean(dim=1) + p[prefix + "bias"]            # :71-74
-    return out, ei, alpha, xlin
+    return out, ei, alpha, xlin_msg
 
 
 # ------------------------------------------------------------------ batch norm
@@ -128,11 +142,16 @@ def out_layer(p: dict, x: torch.Tensor, layer_num: int, training: bool, new_stat
 # ------------------------------------------------------------------ full forward
 def forward(p: dict, data: torch.Tensor, topk: int, out_layer_num: int = 1, *,
             training: bool = False, dropout_mask: torch.Tensor | None = None,
-            graph: torch.Tensor | None = None) -> dict:
+            graph: torch.Tensor | None = None, storage: str = "fp32", round_agg: bool = False) -> dict:
     """models/GDN.py:122-187.  `graph` overrides the top-k result (kernel-level parity
     with an injected neighbour list); `dropout_mask` ([B,N,D], already scaled by 1/(1-p))
-    replaces nn.Dropout's RNG when training.  Returns every intermediate the tests pin."""
+    replaces nn.Dropout's RNG when training.  Returns every intermediate the tests pin.
+    `storage="bf16"`: the input windows and the projected features are stored in bf16 (see
+    graph_layer); `round_agg` additionally rounds the aggregate z to bf16 (the staged pipeline stores it,
+    the fused kernel keeps it on chip in fp32).  Everything else stays fp32."""
     x = data.clone().detach()                               # :124
+    if storage == "bf16":
+        x = round_bf16(x)
     b, n, w = x.shape
     x = x.view(-1, w).contiguous()                          # :130
     emb = p["embedding.weight"]                             # :143 (arange lookup = the table)
@@ -141,7 +160,9 @@ def forward(p: dict, data: torch.Tensor, topk: int, out_layer_num: int = 1, *,
     ei = batched_edge_index(g, b)                           # :161-165
     new_stats: dict = {}
     pre = "gnn_layers.0.gnn."
-    agg, ei1, alpha, xlin = graph_layer(p, pre, x, ei, emb_rep)           # :73
+    agg, ei1, alpha, xlin = graph_layer(p, pre, x, ei, emb_rep, storage)  # :73
+    if round_agg:
+        agg = round_bf16(agg)
     h = F.relu(batch_norm(p, "gnn_layers.0.bn.", agg, training, new_stats))   # :77-79
     h = h.view(b, n, -1)                                    # :171-172
     h = h * emb                                             # :175-176

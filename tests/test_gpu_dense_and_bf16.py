@@ -1,0 +1,184 @@
+"""GPU suite: the matrix-core ("dense") kernels of gdn_amd/csrc/gdn_forward_dense.hip — fused forward,
+staged projection and gather-aggregate — and the bf16-STORAGE variants BASELINE.json configs[2] / configs[4]
+name, against the oracle.
+
+fp32 storage: north_star's bar is 1e-4; the dense kernels split both factors of every product into two f16
+terms (fp32-grade) and are held to the same 2e-5 / 2e-6-vs-float64 bars as the VALU kernels.
+
+bf16 storage (include/gdn_hip.h "bf16 STORAGE variants"): the oracle is fed the same bf16 inputs and rounds
+xlin (and, staged, z) to bf16 where the kernels store them.  TOLERANCE, stated here because neither the
+reference nor north_star defines one for bf16: stored tensors must equal the oracle's bf16 values except for
+<= 0.2 % of the elements, which may differ by ONE bf16 ulp (the fp32 value behind a stored number sits on a
+rounding boundary, and the kernels' fp32 summation order is not the oracle's); final predictions within 2e-4
+absolute (observed <= 5e-5; the bf16 storage itself moves predictions by ~3e-5 relative to the fp32 path)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, meta
+from oracle import gdn_oracle
+from test_gpu_forward_parity import build_model, random_params
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [dict(b=16, n=127, w=15, k=30), dict(b=64, n=27, w=5, k=5), dict(b=8, n=64, w=15, k=63),
+          dict(b=5, n=100, w=30, k=40), dict(b=3, n=33, w=12, k=1), dict(b=700, n=51, w=15, k=15)]
+IDS = ["b{b}_n{n}_w{w}_k{k}".format(**s) for s in SHAPES]
+
+
+def f64_params(p):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in p.items()}
+
+
+def setup(shape, device, seed=5):
+    model = random_params(shape["n"], shape["w"], shape["k"], 64, seed=seed)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(device).eval()
+    x = torch.rand((shape["b"], shape["n"], shape["w"]), generator=torch.Generator().manual_seed(seed + 1))
+    return model, p, x
+
+
+def bf16_ulp(t):
+    """One unit in the last place of the bf16 numbers nearest to t (8 significant bits)."""
+    return torch.exp2(torch.floor(torch.log2(t.abs().clamp_min(1e-30))) - 7)
+
+
+def assert_bf16_stored(got, want, name):
+    got, want = got.float().cpu().double(), want.double()
+    diff = (got - want).abs()
+    bad = diff > 0
+    assert bad.double().mean() <= 2e-3, f"{name}: {bad.double().mean():.2e} of the stored bf16 values differ"
+    assert bool((diff[bad] <= 1.01 * bf16_ulp(want[bad])).all()), f"{name}: a stored value is off by more than one bf16 ulp"
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_dense_staged_kernels_fp32_against_float64_oracle(shape, gpu_device):
+    """gdn_project_fwd / gdn_attn_aggregate_fwd / gdn_head_fwd on the matrix-core path (these shapes all
+    take it) against the float64 oracle, intermediate by intermediate."""
+    from gdn_amd import ops
+    model, p, x = setup(shape, gpu_device)
+    c = model._constants()
+    gnn, lin = model.gnn_layers[0].gnn, model.out_layer.mlp[0]
+    ref = gdn_oracle.forward(f64_params(p), x.double(), shape["k"], graph=c.graph.topk.cpu())
+    xlin, s_i, s_j = ops.project_fwd(x.to(gpu_device), gnn.lin.weight, c.terms)
+    np.testing.assert_allclose(xlin.cpu().double().numpy(), ref["xlin"].numpy(), atol=2e-6, rtol=1e-5)
+    z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=True)
+    np.testing.assert_allclose(z.cpu().double().numpy(), ref["agg"].numpy(), atol=2e-6, rtol=1e-5)
+    layer = model.gnn_layers[0]
+    layer._set_dense((alpha, c.graph, shape["b"]))
+    np.testing.assert_allclose(layer.att_weight_1.cpu().double().numpy(), ref["att_weight_1"].numpy(), atol=2e-6, rtol=0)
+    a = alpha.cpu()
+    np.testing.assert_allclose(a.sum(1).numpy(), 1.0, atol=1e-5)
+    pad = torch.arange(c.graph.pitch).view(1, -1) >= c.graph.deg.cpu().view(-1, 1)
+    assert float(a.view(shape["b"], shape["n"], -1)[:, pad].abs().max()) == 0.0      # padding slots exactly 0
+    out, _ = ops.head_fwd(z, model.embedding.weight, c.bn1, c.bn2, lin.weight, lin.bias, shape["b"])
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:3], ids=IDS[:3])
+def test_dense_kernels_are_deterministic_and_alpha_is_a_pure_side_output(shape, gpu_device):
+    """Same launch twice = same bits; asking for the attention weights does not change z; the fused kernel
+    gives the same bits for a window whatever launch it is part of."""
+    from gdn_amd import ops
+    model, _p, x = setup(shape, gpu_device)
+    c = model._constants()
+    gnn = model.gnn_layers[0].gnn
+    xd = x.to(gpu_device)
+    xlin, s_i, s_j = ops.project_fwd(xd, gnn.lin.weight, c.terms)
+    xlin2, s_i2, s_j2 = ops.project_fwd(xd, gnn.lin.weight, c.terms)
+    assert torch.equal(xlin, xlin2) and torch.equal(s_i, s_i2) and torch.equal(s_j, s_j2)
+    z0, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=False)
+    z1, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=False)
+    z2, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=True)
+    assert torch.equal(z0, z1)
+    assert torch.equal(z0, z2)
+    with torch.no_grad():
+        o0, o1 = model(xd, None), model(xd, None)
+        o2 = model(xd[1:3].contiguous(), None)
+    assert torch.equal(o0, o1) and torch.equal(o0[1:3], o2)
+
+
+def test_valu_and_dense_fused_paths_agree(gpu_device):
+    """The fp32 VALU row-gather kernel (GDN_FUSED_PATH=valu, also the path of every shape the dense kernels
+    do not take) and the matrix-core kernel on the same inputs, in two processes (the choice is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests');"
+            "from test_gpu_forward_parity import random_params;"
+            "m = random_params(127, 15, 30, 64, seed=2).to('cuda:0').eval();"
+            "x = torch.rand((64, 127, 15), generator=torch.Generator().manual_seed(3)).to('cuda:0');"
+            "torch.save(m(x, None).cpu(), sys.argv[1])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for path in ("dense", "valu"):
+        f = f"/tmp/gdn_path_{path}.pt"
+        subprocess.run([sys.executable, "-c", code % (root, root), f], check=True,
+                       env=dict(os.environ, GDN_FUSED_PATH=path))
+        outs.append(torch.load(f, weights_only=True))
+    assert not torch.equal(outs[0], outs[1])             # really two implementations
+    np.testing.assert_allclose(outs[0].numpy(), outs[1].numpy(), atol=4e-6, rtol=0)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_bf16_storage_fused_forward(shape, gpu_device):
+    """GDN.forward on bfloat16 windows (bf16 storage of x and of the LDS-resident projected tile)."""
+    model, p, x = setup(shape, gpu_device)
+    xb = x.bfloat16()
+    with torch.no_grad():
+        out = model(xb.to(gpu_device), None)
+    assert out.dtype == torch.float32
+    graph = model.learned_graph.cpu()
+    ref = gdn_oracle.forward(f64_params(p), xb.double(), shape["k"], graph=graph, storage="bf16")
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4, rtol=0)
+    fp32 = gdn_oracle.forward(f64_params(p), x.double(), shape["k"], graph=graph)
+    assert float((out.cpu().double() - fp32["out"]).abs().max()) < 5e-3   # storage precision, not garbage
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_bf16_storage_staged_pipeline(shape, gpu_device):
+    """gdn_project_fwd_bf16 -> gdn_attn_aggregate_fwd_bf16 -> gdn_head_fwd_bf16, every stored tensor."""
+    from gdn_amd import ops
+    model, p, x = setup(shape, gpu_device)
+    c = model._constants()
+    gnn, lin = model.gnn_layers[0].gnn, model.out_layer.mlp[0]
+    xb = x.bfloat16()
+    ref = gdn_oracle.forward(f64_params(p), xb.double(), shape["k"], graph=c.graph.topk.cpu(), storage="bf16",
+                             round_agg=True)
+    xlin, s_i, s_j = ops.project_fwd(xb.to(gpu_device), gnn.lin.weight, c.terms)
+    assert xlin.dtype == torch.bfloat16
+    assert_bf16_stored(xlin, ref["xlin"], "xlin")
+    # the scalars come from the unrounded projection: s = x.a + c (graph_layer.py:94-104 folded)
+    p64 = f64_params(p)
+    d = 64
+    full = xb.double().view(-1, shape["w"]) @ p64["gnn_layers.0.gnn.lin.weight"].T
+    emb = p64["embedding.weight"]
+    want_si = (full @ p64["gnn_layers.0.gnn.att_i"].view(d)).view(shape["b"], -1) + emb @ p64["gnn_layers.0.gnn.att_em_i"].view(d)
+    np.testing.assert_allclose(s_i.cpu().double().numpy(), want_si.reshape(-1).numpy(), atol=2e-6, rtol=1e-5)
+    z, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=False)
+    assert z.dtype == torch.bfloat16
+    assert_bf16_stored(z, ref["agg"], "z")
+    out, _ = ops.head_fwd(z, model.embedding.weight, c.bn1, c.bn2, lin.weight, lin.bias, shape["b"])
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4, rtol=0)
+
+
+def test_bf16_storage_at_baseline_config2_batch_512(gpu_device):
+    """BASELINE configs[2] as worded: 127 sensors, top-k 30, W=15, batch 512, bf16 — on the fixture's
+    parameters; the fp32 reference output bounds how far bf16 storage may move a prediction."""
+    from test_oracle_golden import full_batch_input
+    data, p = load_golden("cfg2_swat127_w15_k30_b512")
+    m = meta(data)
+    model = build_model(p, m, gpu_device)
+    xb = full_batch_input(data).bfloat16()
+    with torch.no_grad():
+        out = model(xb.to(gpu_device), None)
+    ref = gdn_oracle.forward(f64_params(p), xb.double(), m["k"], graph=model.learned_graph.cpu(), storage="bf16")
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out.cpu().numpy(), data["eval_out"], atol=2e-3, rtol=0)
+
+
+def test_bf16_storage_refuses_shapes_outside_the_matrix_core_path(gpu_device):
+    from gdn_amd._lib import GdnHipError
+    model = random_params(300, 12, 20, 64, seed=1).to(gpu_device).eval()
+    with pytest.raises(GdnHipError, match="UNSUPPORTED"):
+        model(torch.rand((2, 300, 12), device=gpu_device).bfloat16(), None)
