@@ -82,31 +82,33 @@ def event_time_launches(launch, count, settle_ms=60.0):
 
 
 def pmc_traffic(kernel_key, batch):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) for this launch size, or None."""
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) for this launch size, or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             rec = json.load(f)["per_launch"][kernel_key][str(batch)]
         return int(rec["fetch_bytes"] + rec["write_bytes"])
     except (OSError, KeyError, ValueError):
         return None
 
 
-def k8_roofline(model, x, batch, launches):
-    """Staged eval pipeline leg (project -> attention/aggregate -> head); returns the roofline
-    object of the gather-aggregate kernel at this launch size."""
+def k8_roofline(model, x, batch, launches, storage="fp32"):
+    """Staged eval pipeline leg (project -> attention/aggregate -> head); returns the roofline object of
+    the gather-aggregate kernel at this launch size.  storage = "fp32" | "bf16" (x, xlin, z in HBM)."""
     from gdn_amd import _lib, ops
     c = model._constants()
     gnn = model.gnn_layers[0].gnn
     lin = model.out_layer.mlp[0]
     emb = model.embedding.weight
-    xs = x[:batch]
+    sfx = "_bf16" if storage == "bf16" else ""
+    esz = 2 if storage == "bf16" else 4
+    xs = x[:batch].bfloat16() if storage == "bf16" else x[:batch]
     xlin, s_i, s_j = ops.project_fwd(xs, gnn.lin.weight, c.terms)
     z = torch.empty_like(xlin)
     st = torch.cuda.current_stream().cuda_stream
 
     def k8(_i):
-        _lib.call("gdn_attn_aggregate_fwd", xlin.data_ptr(), s_i.data_ptr(), s_j.data_ptr(),
+        _lib.call("gdn_attn_aggregate_fwd" + sfx, xlin.data_ptr(), s_i.data_ptr(), s_j.data_ptr(),
                   c.graph.nbr.data_ptr(), c.graph.deg.data_ptr(), gnn.bias.data_ptr(),
                   batch, N_SENSORS, DIM, TOPK, z.data_ptr(), None, st)
 
@@ -116,27 +118,28 @@ def k8_roofline(model, x, batch, launches):
     out = torch.empty((batch, N_SENSORS), device=x.device)
 
     def proj(_i):
-        _lib.call("gdn_project_fwd", xs.data_ptr(), gnn.lin.weight.data_ptr(), c.terms.data_ptr(), batch,
+        _lib.call("gdn_project_fwd" + sfx, xs.data_ptr(), gnn.lin.weight.data_ptr(), c.terms.data_ptr(), batch,
                   N_SENSORS, WINDOW, DIM, xlin.data_ptr(), s_i.data_ptr(), s_j.data_ptr(), st)
 
     def head(_i):
-        _lib.call("gdn_head_fwd", z.data_ptr(), emb.data_ptr(), c.bn1.data_ptr(), c.bn2.data_ptr(),
+        _lib.call("gdn_head_fwd" + sfx, z.data_ptr(), emb.data_ptr(), c.bn1.data_ptr(), c.bn2.data_ptr(),
                   lin.weight.data_ptr(), lin.bias.data_ptr(), batch, N_SENSORS, DIM, out.data_ptr(), None, st)
     proj_us, _ = event_time_launches(proj, launches)
     head_us, _ = event_time_launches(head, launches)
     # read xlin once + write z once + the neighbour lists once (alpha fused, not stored)
-    alg_bytes = 2 * batch * N_SENSORS * DIM * 4 + N_SENSORS * c.graph.pitch * 2
+    alg_bytes = 2 * batch * N_SENSORS * DIM * esz + N_SENSORS * c.graph.pitch * 2
     achieved = alg_bytes / (mean_us * 1e-6) / 1e9
-    return {"kernel": "gdn_attn_aggregate_fwd (K8 gather-aggregate, staged eval leg, fp32 storage)",
+    return {"kernel": f"gdn_attn_aggregate_fwd{sfx} (K8 gather-aggregate on the matrix cores, staged eval leg, "
+                      f"{storage} storage of xlin and z)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k8", batch),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k8" + sfx, batch),
             "launch_us": round(mean_us, 2), "launch_us_best": round(med_us, 2), "batch": batch,
             "algorithmic_bytes_per_launch": alg_bytes,
             "staged_pipeline_us": {"project": round(proj_us, 2), "attn_aggregate": round(mean_us, 2),
                                    "head": round(head_us, 2)}}
 
 
-def fused_roofline(model, x, pred, batch, launches):
+def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
     from gdn_amd import _lib
     c = model._constants()
     gnn = model.gnn_layers[0].gnn
@@ -146,27 +149,29 @@ def fused_roofline(model, x, pred, batch, launches):
     fixed = (gnn.lin.weight.data_ptr(), c.terms.data_ptr(), c.graph.nbr.data_ptr(), c.graph.deg.data_ptr(),
              gnn.bias.data_ptr(), emb.data_ptr(), c.bn1.data_ptr(), c.bn2.data_ptr(), lin.weight.data_ptr(),
              lin.bias.data_ptr())
-    xstride, pstride = N_SENSORS * WINDOW * 4, N_SENSORS * 4
+    esz = 2 if storage == "bf16" else 4
+    name = "gdn_forward_fused_bf16" if storage == "bf16" else "gdn_forward_fused"
+    xs = x.bfloat16() if storage == "bf16" else x
+    xstride, pstride = N_SENSORS * WINDOW * esz, N_SENSORS * 4
     nslots = max(1, x.shape[0] // batch)
 
     def launch(i):          # raw C-ABI call: host cost per launch stays below the kernel's duration
         s = (i % nslots) * batch
-        _lib.call("gdn_forward_fused", x.data_ptr() + s * xstride, *fixed, batch, N_SENSORS, WINDOW, DIM, TOPK,
+        _lib.call(name, xs.data_ptr() + s * xstride, *fixed, batch, N_SENSORS, WINDOW, DIM, TOPK,
                   pred.data_ptr() + s * pstride, st)
     for i in range(3):
         launch(i)
     mean_us, med_us = event_time_launches(launch, launches)
-    alg_bytes = batch * N_SENSORS * WINDOW * 4 + batch * N_SENSORS * 4    # SURVEY §8d "fused forward"
+    alg_bytes = batch * N_SENSORS * WINDOW * esz + batch * N_SENSORS * 4    # SURVEY §8d "fused forward"
     achieved = alg_bytes / (mean_us * 1e-6) / 1e9
-    # what actually bounds it: the LDS gather (one 16-B read per lane per neighbour) and fp32 VALU
-    lds_bytes = batch * N_SENSORS * 32 * DIM * 4
-    return {"kernel": "gdn_forward_fused (dominant kernel of the timed region; serial launches)", "bound": "hbm",
+    return {"kernel": f"{name} (dominant kernel of the timed region; serial launches)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused", batch),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused" + ("_bf16" if storage == "bf16" else ""), batch),
             "launch_us": round(mean_us, 2), "launch_us_best": round(med_us, 2), "batch": batch,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "by design only x-in + out touch HBM; the kernel is bound by the LDS row gather / fp32 VALU",
-            "lds_gather_TBps": round(lds_bytes / (mean_us * 1e-6) / 1e12, 2)}
+            "algorithmic_bytes_per_launch": alg_bytes, "windows_per_s": round(batch / (mean_us * 1e-6), 1),
+            "note": "by design only x-in + out touch HBM; the aggregation runs as a dense [n x n] x [n x d] product on "
+                    "v_mfma_f32_32x32x16 (two 16-bit terms per factor), bound by LDS operand traffic + VALU "
+                    "(profiles/r02_sq_counters*.json)"}
 
 
 def train_step_line(device, n, w, batch, steps=50):
@@ -309,6 +314,9 @@ def run():
         del xbig
         torch.cuda.empty_cache()
     fused_leg = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch))
+    # BASELINE configs[2] says bf16: the same kernels with x / xlin / z stored in bf16 (fp32 arithmetic)
+    sweep_bf16 = [k8_roofline(model, x, b, launches=launches_for(b), storage="bf16") for b in sorted({batch, launch_batch, t})]
+    fused_leg_bf16 = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch), storage="bf16")
 
     def timed(fn, steps):
         """`steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
@@ -374,12 +382,25 @@ def run():
         result["roofline_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
                                      "launch_us": r["launch_us"]} for r in sweep]
         result["roofline_fused"] = fused_leg
+        result["roofline_bf16"] = next(r for r in sweep_bf16 if r["batch"] == launch_batch)
+        result["roofline_bf16_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
+                                          "launch_us": r["launch_us"]} for r in sweep_bf16]
+        result["roofline_fused_bf16"] = fused_leg_bf16
         if args.coalesce > 1 and world == 1:      # transparency: the same step with one launch per logical minibatch
             ev1 = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams)
             for _ in range(args.warmup):
                 ev1.step()
             preroll(ev1.step)
             result["value_per_batch_launches"] = round(t * args.steps / timed(ev1.step, args.steps), 1)
+    if rank == 0 and world == 1:
+        # the same step on bf16-stored windows (BASELINE configs[2] wording; `value` stays the fp32 line)
+        evb = harness.SeriesEvaluator(model, x.bfloat16(), y, batch=batch, use_graph=not args.no_graph,
+                                      streams=args.streams, coalesce=args.coalesce)
+        for _ in range(args.warmup):
+            evb.step()
+        preroll(evb.step)
+        result["value_bf16_storage"] = round(t * args.steps / timed(evb.step, args.steps), 1)
+        del evb
     if rank == 0 and world == 1:
         # the same step with the windows built in-kernel from the raw [N, T+W] series
         raw = torch.rand((N_SENSORS, t + WINDOW), generator=torch.Generator().manual_seed(7)).to(device)

@@ -58,9 +58,13 @@ struct Fmt;
 
 template <>
 struct Fmt<FMT_F16> {
+  // round to nearest even; one fixed instruction (left to instruction selection, the same source gives
+  // v_cvt_pk_f16_f32 in one kernel variant and two v_cvt_f16_f32 in another, and results that must be
+  // bit-identical across variants are not)
   static __device__ __forceinline__ unsigned pk(float a, float b) {
-    const h2 p = {(_Float16)a, (_Float16)b};   // v_cvt_pk_f16_f32, round to nearest even
-    return __builtin_bit_cast(unsigned, p);
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
   }
   // x - float(half of p): exact in fp32 (p is x rounded to 11 bits), one v_fma_mix_f32
   static __device__ __forceinline__ float res0(unsigned p, float x) {
@@ -81,8 +85,9 @@ struct Fmt<FMT_F16> {
 template <>
 struct Fmt<FMT_BF16> {
   static __device__ __forceinline__ unsigned pk(float a, float b) {
-    const b2 p = {(__bf16)a, (__bf16)b};       // v_cvt_pk_bf16_f32, round to nearest even
-    return __builtin_bit_cast(unsigned, p);
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // round to nearest even
+    return r;
   }
   static __device__ __forceinline__ float res0(unsigned p, float x) { return x - __uint_as_float(p << 16); }
   static __device__ __forceinline__ float res1(unsigned p, float x) { return x - __uint_as_float(p & 0xffff0000u); }
