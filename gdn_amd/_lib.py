@@ -33,6 +33,10 @@ SIGNATURES = {
     "gdn_mse_loss_grad": [_p, _p, ctypes.c_longlong, _p, _p, _p, _p],
     "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],
     "gdn_forward_fused_series": [_p, _c_int, _c_int] + [_p] * 10 + [_c_int] * 5 + [_p, _p],
+    "gdn_fused_plan_bytes": [_c_int] * 5,
+    "gdn_fused_plan_build": [_p] * 10 + [_c_int] * 5 + [_p, _p],
+    "gdn_forward_fused_plan": [_p, _p] + [_c_int] * 6 + [_p, _p],
+    "gdn_forward_fused_series_plan": [_p, _c_int, _c_int, _p] + [_c_int] * 5 + [_p, _p],
     "gdn_project_fwd_bf16": [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p],
     "gdn_attn_aggregate_fwd_bf16": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_head_fwd_bf16": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],

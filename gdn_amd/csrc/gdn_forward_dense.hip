@@ -58,24 +58,28 @@ struct Fmt;
 
 template <>
 struct Fmt<FMT_F16> {
-  // round to nearest even; one fixed instruction (left to instruction selection, the same source gives
-  // v_cvt_pk_f16_f32 in one kernel variant and two v_cvt_f16_f32 in another, and results that must be
-  // bit-identical across variants are not)
+  // round to nearest even (v_cvt_pk_f16_f32 or two v_cvt_f16_f32).  NOT inline asm: the result is an MFMA
+  // operand, and hipcc inserts the VALU-write -> MFMA-read wait states only for instructions it can see (an
+  // asm conversion directly in front of the product fed it stale registers: wrong first column block)
   static __device__ __forceinline__ unsigned pk(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    const h2 p = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, p);
   }
-  // x - float(half of p): exact in fp32 (p is x rounded to 11 bits), one v_fma_mix_f32
+  // x - float(half of p): exact in fp32 (p is x rounded to 11 bits).  Plain C (v_cvt_f32_f16 + v_sub, or a
+  // v_fma_mix the compiler picks itself): hipcc pads hazards only around instructions it can see
+  // x - float(half) as fma(float(half), -1, x) with the -1 hidden from the optimiser in a scalar register
+  // (an EMPTY asm: nothing executes in it), so that instruction selection sees fma(fpext(f16), s, f32) and
+  // emits ONE v_fma_mix_f32 instead of v_cvt_f32_f16 + v_sub_f32 (the split is ~25 % of the kernel's VALU work)
+  static __device__ __forceinline__ float neg_one() {
+    float v = -1.0f;
+    asm("" : "+s"(v));
+    return v;
+  }
   static __device__ __forceinline__ float res0(unsigned p, float x) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
-    return r;
+    return __builtin_fmaf((float)__builtin_bit_cast(h2, p)[0], neg_one(), x);
   }
   static __device__ __forceinline__ float res1(unsigned p, float x) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
-    return r;
+    return __builtin_fmaf((float)__builtin_bit_cast(h2, p)[1], neg_one(), x);
   }
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
@@ -85,9 +89,8 @@ struct Fmt<FMT_F16> {
 template <>
 struct Fmt<FMT_BF16> {
   static __device__ __forceinline__ unsigned pk(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // round to nearest even
-    return r;
+    const b2 p = {(__bf16)a, (__bf16)b};       // v_cvt_pk_bf16_f32, round to nearest even (not asm: see above)
+    return __builtin_bit_cast(unsigned, p);
   }
   static __device__ __forceinline__ float res0(unsigned p, float x) { return x - __uint_as_float(p << 16); }
   static __device__ __forceinline__ float res1(unsigned p, float x) { return x - __uint_as_float(p & 0xffff0000u); }
@@ -169,6 +172,7 @@ struct DArgs {
   const float* out_w;       // [d]
   const float* out_b;       // [1]
   float* out;               // [B, n]
+  const unsigned* plan;     // gdn_fused_plan_build output, or null
 };
 
 __device__ __forceinline__ float lds_f32(const char* smem, int byte_off) {
@@ -227,10 +231,174 @@ __device__ __forceinline__ void scatter_terms(char* smem, const int (&scoff)[SL]
   }
 }
 
+#ifdef GDN_STAMPS   // diagnostic build only: shader-clock stamps of workgroup 0 / wave 0 (tools/probe_stamps.py)
+__device__ unsigned long long g_dense_stamps[64];
+#define GDN_STAMP(i)                                                                      \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                              \
+    unsigned long long t_;                                                                \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    g_dense_stamps[i] = t_;                                                               \
+  }
+#else
+#define GDN_STAMP(i)
+#endif
+
 // clamped unconditional global load + select: the prologue's loads all issue back to back
 __device__ __forceinline__ float ld_or(const float* p, int idx, bool ok, float other = 0.f) {
   const float v = p[ok ? idx : 0];
   return ok ? v : other;
+}
+
+// ---- per-launch constants of the fused kernel -----------------------------------------------------
+// Everything a lane keeps in registers for the whole launch (list offsets, weight operand fragments,
+// epilogue factors) and the two small LDS tables depend only on the parameters and on the sensor graph,
+// not on the windows.  They are computed ONCE per parameter update by gdn_fused_plan_build into a
+// "plan" in device memory (lane-major words, so a workgroup's prologue is ~90 coalesced dword loads per
+// lane instead of ~1000 VALU instructions and a chain of dependent gathers); gdn_forward_fused without a
+// plan computes them in the prologue of every workgroup (same code, DArgs::plan == null).
+template <int NT, int DC, int WK, int SL, int FMT>
+struct LaneConsts {
+  using C = DCfg<NT, DC, WK, SL, FMT>;
+  int sjoff[SL], scoff[SL];
+  u32x4 bl[DC][WK][C::NTL], bs[WK][C::NTL];
+  float cin[DC];
+  float e2[DC][16];
+  float out_b;
+  static constexpr int WORDS = 2 * SL + 4 * (DC * WK * C::NTL + WK * C::NTL) + DC + 16 * DC + 1;
+  static constexpr int TABLE_WORDS = 4 * 32 * DC + 3 * C::ROWS;     // [ec | cs] as they sit in LDS
+  static constexpr size_t PLAN_BYTES = ((size_t)TABLE_WORDS + (size_t)WORDS * C::THREADS) * 4;
+
+  // visits every 32-bit word in a fixed order: f(word index, reference to the word as unsigned)
+  template <class Fn>
+  __device__ __forceinline__ void each_word(Fn&& f) {
+    int i = 0;
+#pragma unroll
+    for (int q = 0; q < SL; ++q) f(i++, reinterpret_cast<unsigned&>(sjoff[q]));
+#pragma unroll
+    for (int q = 0; q < SL; ++q) f(i++, reinterpret_cast<unsigned&>(scoff[q]));
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int wk = 0; wk < WK; ++wk)
+#pragma unroll
+        for (int t = 0; t < C::NTL; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned tmp = bl[cb][wk][t][e];
+            f(i++, tmp);
+            bl[cb][wk][t][e] = tmp;
+          }
+#pragma unroll
+    for (int wk = 0; wk < WK; ++wk)
+#pragma unroll
+      for (int t = 0; t < C::NTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned tmp = bs[wk][t][e];
+          f(i++, tmp);
+          bs[wk][t][e] = tmp;
+        }
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb) f(i++, reinterpret_cast<unsigned&>(cin[cb]));
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f(i++, reinterpret_cast<unsigned&>(e2[cb][r]));
+    f(i++, reinterpret_cast<unsigned&>(out_b));
+  }
+};
+
+template <int NT, int DC, int WK, int SL, int FMT>
+__device__ __forceinline__ void compute_lane_consts(const DArgs& a, LaneConsts<NT, DC, WK, SL, FMT>& k) {
+  using C = DCfg<NT, DC, WK, SL, FMT>;
+  constexpr bool FOLD = FMT == FMT_F16;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int n = a.n, w = a.w, d = 32 * DC;
+  // S: this lane's half of one target's neighbour list
+  const int ti = 32 * wv + (lane >> 1);
+  const int half = lane & 1;
+  {
+    const uint16_t* row = a.nbr + (size_t)min(ti, n - 1) * a.pitch + half * SL;
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+      const int jj = (int)row[q];
+      const int j = ti < n ? jj : n;
+      k.sjoff[q] = C::OFF_SJ + j * 4;
+      k.scoff[q] = C::OFF_A + wv * C::AWAVE + (lane >> 1) * C::AROW + pos_of_source(j) * 2;
+    }
+  }
+  // P: B operand = lin'^T (k on the registers, output column on the lane), split once
+#pragma unroll
+  for (int cb = 0; cb < DC; ++cb) {
+    const int c = cb * 32 + l32;
+    const float sc = FOLD ? a.bn1[c] * GDN_F16_X_SCALE : 1.f;
+    k.cin[cb] = FOLD ? fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]) * GDN_F16_X_SCALE : 0.f;
+#pragma unroll
+    for (int wk = 0; wk < WK; ++wk) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kk = wk * 16 + 8 * h + j;
+        v[j] = ld_or(a.lin_w, c * w + kk, kk < w) * sc;
+      }
+      split8<FMT, C::NTL>(v, k.bl[cb][wk]);
+    }
+  }
+#pragma unroll
+  for (int wk = 0; wk < WK; ++wk) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = wk * 16 + 8 * h + j;   // a_i / a_j are stored zero padded to 64
+      v[j] = ld_or(a.node_terms, l32 * GDN_A_PITCH + kk, l32 < 2) * GDN_LOG2E;
+    }
+    split8<FMT, C::NTL>(v, k.bs[wk]);
+  }
+  // E: embedding x BatchNorm scale of this lane's target, per (column block, register)
+  const int tgt = 32 * wv + l32;
+#pragma unroll
+  for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      k.e2[cb][r] = ld_or(a.emb, tgt * d + c, tgt < n) * a.bn2[c] *
+                    (FMT == FMT_F16 ? 1.f / (GDN_F16_ALPHA_SCALE * GDN_F16_X_SCALE) : 1.f);
+    }
+  k.out_b = a.out_b[0];
+}
+
+// the two LDS tables, written to `dst` (LDS or the plan): epilogue column constants
+// [sh2 | out_w | sc1 | sh1'] (the last two are used without the BatchNorm fold), then the C-in of the
+// scalar tile [c_i | c_j | zeros][ROWS] in the log2 domain (row n, the list sentinel, gets s_j = -inf;
+// the lanes of the 30 unused columns read the zero row)
+template <int NT, int DC>
+__device__ __forceinline__ void compute_tables(const DArgs& a, float* dst) {
+  constexpr int ROWS = 32 * NT, THREADS = 64 * NT, d = 32 * DC;
+  const int tid = threadIdx.x, n = a.n;
+  for (int c = tid; c < d; c += THREADS) {
+    dst[c] = a.bn2[d + c];
+    dst[d + c] = a.out_w[c];
+    dst[2 * d + c] = a.bn1[c];
+    dst[3 * d + c] = fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]);
+  }
+  float* ct = dst + 4 * d;
+  for (int t = tid; t < 3 * ROWS; t += THREADS) {
+    const int which = t / ROWS, row = t - which * ROWS;
+    float v = ld_or(a.node_terms, 2 * GDN_A_PITCH + which * n + row, which < 2 && row < n) * GDN_LOG2E;
+    if (which == 1 && row == n) v = -INFINITY;
+    ct[t] = v;
+  }
+}
+
+template <int NT, int DC, int WK, int SL, int FMT>
+__global__ __launch_bounds__(64 * NT) void gdn_dense_plan_kernel(const DArgs a, unsigned* plan) {
+  using K = LaneConsts<NT, DC, WK, SL, FMT>;
+  K k;
+  compute_lane_consts(a, k);
+  compute_tables<NT, DC>(a, reinterpret_cast<float*>(plan));
+  unsigned* lanes = plan + K::TABLE_WORDS;
+  k.each_word([&](int i, unsigned& wd) { lanes[i * (64 * NT) + threadIdx.x] = wd; });
 }
 
 template <int NT, int DC, int WK, int SL, int FMT>
@@ -245,94 +413,27 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
   const int l32 = lane & 31, h = lane >> 5;
   const int n = a.n, w = a.w, d = 32 * DC;
   constexpr bool FOLD = FMT == FMT_F16;   // bf16 storage rounds xlin itself, so BatchNorm stays in the epilogue
+  GDN_STAMP(0)
 
   // ---------------------------------------------------------------- once per workgroup
   for (int t = lane; t < C::AWAVE / 16; t += 64)
     reinterpret_cast<uint4*>(smem + C::OFF_A + wv * C::AWAVE)[t] = make_uint4(0, 0, 0, 0);
   {   // pad columns CW .. XP-1 of the x tile are never read; columns w .. CW-1 and rows >= n are stored as 0
   }
-  // epilogue column constants [sh2 | out_w | sc1 | sh1'] (the last two only without the BatchNorm fold)
-  {
-    float* ec = reinterpret_cast<float*>(smem + C::OFF_EC);
-    for (int c = tid; c < d; c += C::THREADS) {
-      ec[c] = a.bn2[d + c];
-      ec[d + c] = a.out_w[c];
-      ec[2 * d + c] = a.bn1[c];
-      ec[3 * d + c] = fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]);
-    }
+  // per-launch constants: from the plan, or computed here (gdn_forward_fused without a plan)
+  LaneConsts<NT, DC, WK, SL, FMT> k;
+  if (a.plan) {
+    const unsigned* lanes = a.plan + LaneConsts<NT, DC, WK, SL, FMT>::TABLE_WORDS;
+    k.each_word([&](int i, unsigned& wd) { wd = lanes[i * C::THREADS + tid]; });
+    unsigned* tab = reinterpret_cast<unsigned*>(smem + C::OFF_EC);
+    for (int t = tid; t < LaneConsts<NT, DC, WK, SL, FMT>::TABLE_WORDS; t += C::THREADS) tab[t] = a.plan[t];
+  } else {
+    compute_lane_consts(a, k);
+    compute_tables<NT, DC>(a, reinterpret_cast<float*>(smem + C::OFF_EC));
   }
-
-  // S: this lane's half of one target's neighbour list
-  const int ti = 32 * wv + (lane >> 1);
-  const int half = lane & 1;
-  int sjoff[SL], scoff[SL];
-  {
-    const uint16_t* row = a.nbr + (size_t)min(ti, n - 1) * a.pitch + half * SL;
-#pragma unroll
-    for (int q = 0; q < SL; ++q) {
-      const int jj = (int)row[q];
-      const int j = ti < n ? jj : n;
-      sjoff[q] = C::OFF_SJ + j * 4;
-      scoff[q] = C::OFF_A + wv * C::AWAVE + (lane >> 1) * C::AROW + pos_of_source(j) * 2;
-    }
-  }
-  const int si_off = C::OFF_SI + ti * 4;
-
-  // P: B operand = lin'^T (k on the registers, output column on the lane), split once
-  u32x4 bl[DC][WK][C::NTL], bs[WK][C::NTL];
-  float cin[DC];
-#pragma unroll
-  for (int cb = 0; cb < DC; ++cb) {
-    const int c = cb * 32 + l32;
-    const float sc = FOLD ? a.bn1[c] * GDN_F16_X_SCALE : 1.f;
-    cin[cb] = FOLD ? fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]) * GDN_F16_X_SCALE : 0.f;
-#pragma unroll
-    for (int wk = 0; wk < WK; ++wk) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = wk * 16 + 8 * h + j;
-        v[j] = ld_or(a.lin_w, c * w + k, k < w) * sc;
-      }
-      split8<FMT, C::NTL>(v, bl[cb][wk]);
-    }
-  }
-#pragma unroll
-  for (int wk = 0; wk < WK; ++wk) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = wk * 16 + 8 * h + j;   // a_i / a_j are stored zero padded to 64
-      v[j] = ld_or(a.node_terms, l32 * GDN_A_PITCH + k, l32 < 2) * GDN_LOG2E;
-    }
-    split8<FMT, C::NTL>(v, bs[wk]);
-  }
-  // C-in of the scalar tile, kept in LDS (16 accumulator registers are initialised from it every window):
-  // c_i / c_j of the row's sensor (log2 domain); row n, the list sentinel, gets s_j = -inf; the lanes of
-  // the 30 unused columns read the zero row
-  {
-    float* ct = reinterpret_cast<float*>(smem + C::OFF_CS);
-    for (int t = tid; t < 3 * C::ROWS; t += C::THREADS) {
-      const int which = t / C::ROWS, row = t - which * C::ROWS;
-      float v = ld_or(a.node_terms, 2 * GDN_A_PITCH + which * n + row, which < 2 && row < n) * GDN_LOG2E;
-      if (which == 1 && row == n) v = -INFINITY;
-      ct[t] = v;
-    }
-  }
+  const int si_off = C::OFF_SI + (32 * wv + (lane >> 1)) * 4;
   const int cs_off = C::OFF_CS + (min(l32, 2) * C::ROWS + 32 * wv + 4 * h) * 4;   // + 32 (r >> 2): 4 rows
-
-  // E: embedding x BatchNorm scale of this lane's target, per (column block, register)
   const int tgt = 32 * wv + l32;
-  float e2[DC][16];
-#pragma unroll
-  for (int cb = 0; cb < DC; ++cb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      e2[cb][r] = ld_or(a.emb, tgt * d + c, tgt < n) * a.bn2[c] *
-                  (FMT == FMT_F16 ? 1.f / (GDN_F16_ALPHA_SCALE * GDN_F16_X_SCALE) : 1.f);
-    }
-  const float out_b = a.out_b[0];
 
   // x staging: a thread owns column (tid % CW) of rows row0, row0 + RS, ...; global offsets are one VGPR
   // plus a scalar step per row group (buffer loads: reads past the end of the input return 0), LDS
@@ -367,8 +468,10 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
       }
     }
   };
+  GDN_STAMP(1)
   load_window(blockIdx.x);
   __syncthreads();   // zero fills done
+  GDN_STAMP(2)
 
   const int arow_off = C::OFF_A + wv * C::AWAVE + l32 * C::AROW + h * 16;   // alpha operand of this lane
   const int xrow_off = C::OFF_XS + ((32 * wv + l32) * C::XP + 8 * h) * 4;  // x operand of this lane
@@ -378,8 +481,10 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
 #pragma unroll
     for (int u = 0; u < C::XU; ++u)
       *reinterpret_cast<float*>(smem + xst_off + u * (RS * C::XP * 4)) = xok[u] ? xr[u] : 0.f;
+    if (b == (int)blockIdx.x) { GDN_STAMP(3) }
     __syncthreads();                                           // B1: x tile of window b visible
     load_window(min(b + (int)gridDim.x, a.batch - 1));         // lands under the math (last round: re-read)
+    if (b == (int)blockIdx.x) { GDN_STAMP(4) }
 
     // ------------------------------------------------------------ P
     {
@@ -387,7 +492,7 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
 #pragma unroll
       for (int cb = 0; cb < DC; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[cb][r] = cin[cb];
+        for (int r = 0; r < 16; ++r) acc1[cb][r] = k.cin[cb];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 t = *reinterpret_cast<const float4*>(smem + cs_off + 32 * g);
@@ -408,8 +513,8 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
           for (int tl = 0; tl < C::NTL; ++tl)
             if (tx + tl < (C::NTXIN > C::NTL ? C::NTXIN : C::NTL)) {
 #pragma unroll
-              for (int cb = 0; cb < DC; ++cb) acc1[cb] = F::mfma(ax[tx], bl[cb][wk][tl], acc1[cb]);
-              accs = F::mfma(ax[tx], bs[wk][tl], accs);
+              for (int cb = 0; cb < DC; ++cb) acc1[cb] = F::mfma(ax[tx], k.bl[cb][wk][tl], acc1[cb]);
+              accs = F::mfma(ax[tx], k.bs[wk][tl], accs);
             }
       }
       // attention scalars: columns 0 / 1 of the scalar tile
@@ -433,7 +538,9 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
             *reinterpret_cast<u32x4*>(smem + C::OFF_XF + ((((2 * wv + s) * DC + cb) * C::NPX + t) << 10) + lane * 16) = xf[t];
         }
     }
+    if (b == (int)blockIdx.x) { GDN_STAMP(5) }
     __syncthreads();                                           // B2: tile fragments + scalars visible
+    if (b == (int)blockIdx.x) { GDN_STAMP(6) }
 
     // ------------------------------------------------------------ S
     // log2 domain: a_i, a_j, c_i, c_j carry a factor log2(e) (LeakyReLU commutes with a positive
@@ -441,7 +548,7 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
     unsigned ph[SL / 2], pl[SL / 2];
     {
       float unused[SL];
-      softmax_split<SL, FMT, false>(smem, si_off, sjoff, ph, pl, unused);
+      softmax_split<SL, FMT, false>(smem, si_off, k.sjoff, ph, pl, unused);
     }
     // ------------------------------------------------------------ M
     // The image is wave private and LDS executes one wave's accesses in order: scatter the hi term,
@@ -467,7 +574,8 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
 #pragma unroll
       for (int cb = 0; cb < DC; ++cb) fx[buf][cb][0] = lds_frag(smem, xf_lane + ks * XF_KS + ((cb * C::NPX) << 10));
     };
-    scatter_terms<SL>(smem, scoff, ph);
+    if (b == (int)blockIdx.x) { GDN_STAMP(7) }
+    scatter_terms<SL>(smem, k.scoff, ph);
     __builtin_amdgcn_sched_barrier(0);
     fetch_hi(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -481,7 +589,7 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
         for (int t = 0; t < C::NPX; ++t) acc2[cb] = F::mfma(fx[ks & 1][cb][t], fa[ks & 1], acc2[cb]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    scatter_terms<SL>(smem, scoff, pl);
+    scatter_terms<SL>(smem, k.scoff, pl);
     __builtin_amdgcn_sched_barrier(0);
     fetch_lo(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -494,6 +602,7 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (b == (int)blockIdx.x) { GDN_STAMP(8) }
     // ------------------------------------------------------------ E  (models/GDN.py:77-79,175-184)
     float part = 0.f;
 #pragma unroll
@@ -515,13 +624,15 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
           float v = acc2[cb][4 * g + i];
           if constexpr (!FOLD) v = fmaf(v, sc1a[i], sh1a[i]);
           v = fmaxf(v, 0.f);
-          v = fmaxf(fmaf(v, e2[cb][4 * g + i], sh2a[i]), 0.f);
+          v = fmaxf(fmaf(v, k.e2[cb][4 * g + i], sh2a[i]), 0.f);
           part = fmaf(v, woa[i], part);
         }
       }
     part += __shfl_xor(part, 32);
-    if (h == 0 && tgt < n) a.out[(size_t)b * n + tgt] = part + out_b;
+    if (h == 0 && tgt < n) a.out[(size_t)b * n + tgt] = part + k.out_b;
+    if (b == (int)blockIdx.x) { GDN_STAMP(9) }
   }
+  GDN_STAMP(10)
 }
 
 // ------------------------------------------------------------------ staged gather-aggregate (K8)
@@ -934,10 +1045,22 @@ int cu_count() {
   return cached[dev];
 }
 
+enum { DOP_LAUNCH = 0, DOP_PLAN_BUILD = 1, DOP_PLAN_BYTES = 2 };
+
 template <int NT, int DC, int WK, int SL, int FMT>
-int launch_fused(const DArgs& a, hipStream_t stream) {
+int fused_op(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipStream_t stream) {
   using C = DCfg<NT, DC, WK, SL, FMT>;
+  using K = LaneConsts<NT, DC, WK, SL, FMT>;
   static_assert(C::LDS <= 160 * 1024, "LDS plan exceeds one CU");
+  static_assert(C::OFF_CS == C::OFF_EC + 4 * 32 * DC * 4, "the two LDS tables are one block of the plan");
+  if (op == DOP_PLAN_BYTES) {
+    *bytes = (long long)K::PLAN_BYTES;
+    return GDN_OK;
+  }
+  if (op == DOP_PLAN_BUILD) {
+    hipLaunchKernelGGL((gdn_dense_plan_kernel<NT, DC, WK, SL, FMT>), dim3(1), dim3(C::THREADS), 0, stream, a, plan_out);
+    return gdn_launch_status();
+  }
   auto kern = gdn_dense_fused_kernel<NT, DC, WK, SL, FMT>;
   const int occ = blocks_per_cu(reinterpret_cast<const void*>(kern), C::THREADS, C::LDS);
   const int grid = max(1, min(a.batch, cu_count() * occ));
@@ -946,29 +1069,29 @@ int launch_fused(const DArgs& a, hipStream_t stream) {
 }
 
 template <int NT, int DC, int WK, int FMT>
-int select_sl(const DArgs& a, hipStream_t st) {
+int select_sl(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipStream_t st) {
   switch (a.pitch) {
-    case 16: return launch_fused<NT, DC, WK, 8, FMT>(a, st);
-    case 32: return launch_fused<NT, DC, WK, 16, FMT>(a, st);
-    case 48: return launch_fused<NT, DC, WK, 24, FMT>(a, st);
-    case 64: return launch_fused<NT, DC, WK, 32, FMT>(a, st);
+    case 16: return fused_op<NT, DC, WK, 8, FMT>(op, a, plan_out, bytes, st);
+    case 32: return fused_op<NT, DC, WK, 16, FMT>(op, a, plan_out, bytes, st);
+    case 48: return fused_op<NT, DC, WK, 24, FMT>(op, a, plan_out, bytes, st);
+    case 64: return fused_op<NT, DC, WK, 32, FMT>(op, a, plan_out, bytes, st);
   }
   return GDN_ERR_UNSUPPORTED;
 }
 
 template <int NT, int FMT>
-int select_wk(const DArgs& a, hipStream_t st) {
-  if (a.w <= 16) return select_sl<NT, 2, 1, FMT>(a, st);
-  return select_sl<NT, 2, 2, FMT>(a, st);
+int select_wk(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipStream_t st) {
+  if (a.w <= 16) return select_sl<NT, 2, 1, FMT>(op, a, plan_out, bytes, st);
+  return select_sl<NT, 2, 2, FMT>(op, a, plan_out, bytes, st);
 }
 
 template <int FMT>
-int select_nt(const DArgs& a, hipStream_t st) {
+int select_nt(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipStream_t st) {
   switch ((a.n + 1 + 31) / 32) {
-    case 1: return select_wk<1, FMT>(a, st);
-    case 2: return select_wk<2, FMT>(a, st);
-    case 3: return select_wk<3, FMT>(a, st);
-    case 4: return select_wk<4, FMT>(a, st);
+    case 1: return select_wk<1, FMT>(op, a, plan_out, bytes, st);
+    case 2: return select_wk<2, FMT>(op, a, plan_out, bytes, st);
+    case 3: return select_wk<3, FMT>(op, a, plan_out, bytes, st);
+    case 4: return select_wk<4, FMT>(op, a, plan_out, bytes, st);
   }
   return GDN_ERR_UNSUPPORTED;
 }
@@ -1056,5 +1179,65 @@ int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int se
   a.batch = batch; a.n = n; a.w = w; a.pitch = gdn_nbr_pitch(k); a.d = d;
   a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.gnn_bias = gnn_bias; a.emb = emb;
   a.bn1 = bn1; a.bn2 = bn2; a.out_w = out_w; a.out_b = out_b; a.out = out;
-  return x_is_bf16 ? select_nt<FMT_BF16>(a, stream) : select_nt<FMT_F16>(a, stream);
+  return x_is_bf16 ? select_nt<FMT_BF16>(DOP_LAUNCH, a, nullptr, nullptr, stream)
+                   : select_nt<FMT_F16>(DOP_LAUNCH, a, nullptr, nullptr, stream);
+}
+
+#ifdef GDN_STAMPS
+extern "C" int gdn_debug_read_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dense_stamps), sizeof(g_dense_stamps)) == hipSuccess ? 0 : -2;
+}
+#endif
+
+// ---- plans (C ABI: include/gdn_hip.h) -----------------------------------------------------------------
+extern "C" long long gdn_fused_plan_bytes(int n, int w, int d, int k, int bf16_storage) {
+  if (!gdn_dense_supported(n, w, d, k)) return 0;
+  DArgs a = {};
+  a.n = n; a.w = w; a.d = d; a.pitch = gdn_nbr_pitch(k);
+  long long bytes = 0;
+  const int rc = bf16_storage ? select_nt<FMT_BF16>(DOP_PLAN_BYTES, a, nullptr, &bytes, nullptr)
+                              : select_nt<FMT_F16>(DOP_PLAN_BYTES, a, nullptr, &bytes, nullptr);
+  return rc == GDN_OK ? bytes : 0;
+}
+
+extern "C" int gdn_fused_plan_build(const float* lin_w, const float* node_terms, const uint16_t* nbr,
+                                    const int32_t* deg, const float* gnn_bias, const float* emb,
+                                    const float* bn1_affine, const float* bn2_affine, const float* out_w,
+                                    const float* out_b, int n, int w, int d, int k, int bf16_storage,
+                                    void* plan, void* stream) {
+  if (!lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine || !bn2_affine || !out_w ||
+      !out_b || !plan)
+    return GDN_ERR_ARG;
+  if (!gdn_dense_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
+  DArgs a = {};
+  a.n = n; a.w = w; a.d = d; a.pitch = gdn_nbr_pitch(k);
+  a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.gnn_bias = gnn_bias; a.emb = emb;
+  a.bn1 = bn1_affine; a.bn2 = bn2_affine; a.out_w = out_w; a.out_b = out_b;
+  unsigned* p = reinterpret_cast<unsigned*>(plan);
+  return bf16_storage ? select_nt<FMT_BF16>(DOP_PLAN_BUILD, a, p, nullptr, (hipStream_t)stream)
+                      : select_nt<FMT_F16>(DOP_PLAN_BUILD, a, p, nullptr, (hipStream_t)stream);
+}
+
+static int fused_with_plan(const void* x, int series_len, int first, const void* plan, int batch, int n, int w,
+                           int d, int k, int bf16_storage, float* out, void* stream) {
+  if (!x || !plan || !out) return GDN_ERR_ARG;
+  if (batch <= 0 || n <= 0) return GDN_ERR_ARG;
+  if (!gdn_dense_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
+  DArgs a = {};
+  a.x = x; a.series_len = series_len; a.series_first = first;
+  a.batch = batch; a.n = n; a.w = w; a.pitch = gdn_nbr_pitch(k); a.d = d;
+  a.out = out; a.plan = reinterpret_cast<const unsigned*>(plan);
+  return bf16_storage ? select_nt<FMT_BF16>(DOP_LAUNCH, a, nullptr, nullptr, (hipStream_t)stream)
+                      : select_nt<FMT_F16>(DOP_LAUNCH, a, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int gdn_forward_fused_plan(const void* x, const void* plan, int batch, int n, int w, int d, int k,
+                                      int bf16_storage, float* out, void* stream) {
+  return fused_with_plan(x, 0, 0, plan, batch, n, w, d, k, bf16_storage, out, stream);
+}
+
+extern "C" int gdn_forward_fused_series_plan(const float* series, int series_len, int first, const void* plan,
+                                             int batch, int n, int w, int d, int k, float* out, void* stream) {
+  if (series_len <= 0 || first < 0 || (long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;
+  return fused_with_plan(series, series_len, first, plan, batch, n, w, d, k, 0, out, stream);
 }

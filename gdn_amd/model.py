@@ -193,7 +193,7 @@ class OutLayer(nn.Module):
 
 
 class _EvalConstants:
-    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args")
+    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans")
 
 
 class GDN(nn.Module):
@@ -272,6 +272,7 @@ class GDN(nn.Module):
         c.terms = ops.node_terms(gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i, gnn.att_em_j, emb)
         c.bn1 = c.bn2 = None
         c.fused_args = None
+        c.plans = {}                 # bf16_storage -> plan tensor (or None: shape not on the matrix-core path)
         if not self.training:
             c.bn1 = ops.bn_fold(self.gnn_layers[0].bn)
             c.bn2 = ops.bn_fold(self.bn_outlayer_in)
@@ -294,10 +295,26 @@ class GDN(nn.Module):
         b = x.shape[0]
         if x.shape[1] != n or x.shape[2] != w:
             raise ValueError(f"expected data of shape [B, {n}, {w}], got {tuple(x.shape)}")
-        name = "gdn_forward_fused_bf16" if x.dtype == torch.bfloat16 else "gdn_forward_fused"
-        _lib.call(name, x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(),
-                  torch.cuda.current_stream().cuda_stream)
+        bf16 = x.dtype == torch.bfloat16
+        plan = self._plan(c, bf16)
+        st = torch.cuda.current_stream().cuda_stream
+        if plan is not None:
+            _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, int(bf16),
+                      out.data_ptr(), st)
+        else:
+            _lib.call("gdn_forward_fused_bf16" if bf16 else "gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k,
+                      out.data_ptr(), st)
         return out
+
+    def _plan(self, c, bf16: bool):
+        """The fused kernel's precomputed per-launch constants for these parameters (built on first use,
+        dropped with the constants cache)."""
+        if bf16 not in c.plans:
+            gnn = self.gnn_layers[0].gnn
+            lin = self.out_layer.mlp[0]
+            c.plans[bf16] = ops.fused_plan(gnn.lin.weight, c.terms, c.graph, gnn.bias, self.embedding.weight,
+                                           c.bn1, c.bn2, lin.weight, lin.bias, bf16_storage=bf16)
+        return c.plans[bf16]
 
     # ------------------------------------------------------------------ forward
     def forward(self, data, org_edge_index=None):
@@ -399,6 +416,16 @@ class GDN(nn.Module):
         gnn = self.gnn_layers[0].gnn
         lin = self.out_layer.mlp[0]
         self.learned_graph = c.graph.topk
+        plan = self._plan(c, False)
+        if plan is not None:
+            series = ops._chk(series, name="series")
+            n, t_len = series.shape
+            d, w = gnn.lin.weight.shape
+            if out is None:
+                out = torch.empty((batch, n), dtype=torch.float32, device=series.device)
+            _lib.call("gdn_forward_fused_series_plan", series.data_ptr(), t_len, first, plan.data_ptr(), batch, n, w, d,
+                      c.graph.k, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            return out
         return ops.forward_fused_series(series, first, batch, gnn.lin.weight.shape[1], gnn.lin.weight, c.terms,
                                         c.graph, gnn.bias, self.embedding.weight, c.bn1, c.bn2, lin.weight,
                                         lin.bias, out=out)

@@ -5,6 +5,8 @@ device — there is no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -225,6 +227,26 @@ def forward_fused(x, lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine
               _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
               b, n, w, d, graph.k, _ptr(out), _stream())
     return out
+
+
+def fused_plan(lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
+               bf16_storage: bool = False):
+    """Per-launch constants of the fused forward, precomputed (include/gdn_hip.h "plans"); None when the
+    shape is not on the matrix-core path.  Rebuild after every parameter update."""
+    if os.environ.get("GDN_FUSED_PATH", "").startswith("v"):      # diagnostic: keep the fp32 VALU kernels
+        return None
+    lin_w = _chk(lin_w.detach(), name="lin.weight")
+    d, w = lin_w.shape
+    n = emb.shape[0]
+    nbytes = _lib.load().gdn_fused_plan_bytes(n, w, d, graph.k, int(bf16_storage))
+    if nbytes == 0:
+        return None
+    plan = torch.empty(((nbytes + 3) // 4,), dtype=torch.int32, device=emb.device)
+    _lib.call("gdn_fused_plan_build", _ptr(lin_w), _ptr(terms), _ptr(graph.nbr), _ptr(graph.deg),
+              _ptr(_chk(gnn_bias.detach())), _ptr(_chk(emb.detach())), _ptr(bn1_affine), _ptr(bn2_affine),
+              _ptr(_chk(out_w.detach().reshape(-1))), _ptr(_chk(out_b.detach().reshape(-1))),
+              n, w, d, graph.k, int(bf16_storage), _ptr(plan), _stream())
+    return plan
 
 
 def forward_fused_series(series, first: int, batch: int, w: int, lin_w, terms, graph: SensorGraph, gnn_bias, emb,

@@ -176,6 +176,31 @@ int gdn_forward_fused_series(const float* series, int series_len, int first, con
                              const float* bn2_affine, const float* out_w, const float* out_b,
                              int batch, int n, int w, int d, int k, float* out, void* stream);
 
+/* ---- plans: the fused forward with its per-launch constants precomputed -------------
+ * For shapes on the matrix-core path (n <= 127, d = 64, w <= 32, k <= 63) everything a
+ * workgroup of gdn_forward_fused derives from the parameters and the sensor graph (list
+ * offsets, split weight operands, folded BatchNorm / embedding factors) can be computed
+ * once per parameter update into a caller-owned device buffer, the PLAN; launches that are
+ * given it skip that prologue (~10 us per workgroup), which is most of the time of a
+ * single-minibatch launch.  The plan is read-only for the launches and holds no pointers.
+ *   gdn_fused_plan_bytes   size of the plan for this shape (0 = shape not on this path:
+ *                          use gdn_forward_fused);
+ *   gdn_fused_plan_build   same parameter arguments as gdn_forward_fused;
+ *   gdn_forward_fused_plan / _series_plan   = gdn_forward_fused(_bf16) /
+ *                          gdn_forward_fused_series on the plan's parameters; x is
+ *                          fp32 [batch,n,w] (bf16_storage = 0) or bf16 (1, must match the
+ *                          plan).  Results are bit-identical to the plan-less calls.        */
+long long gdn_fused_plan_bytes(int n, int w, int d, int k, int bf16_storage);
+int gdn_fused_plan_build(const float* lin_w, const float* node_terms, const uint16_t* nbr,
+                         const int32_t* deg, const float* gnn_bias, const float* emb,
+                         const float* bn1_affine, const float* bn2_affine, const float* out_w,
+                         const float* out_b, int n, int w, int d, int k, int bf16_storage,
+                         void* plan, void* stream);
+int gdn_forward_fused_plan(const void* x, const void* plan, int batch, int n, int w, int d, int k,
+                           int bf16_storage, float* out, void* stream);
+int gdn_forward_fused_series_plan(const float* series, int series_len, int first, const void* plan,
+                                  int batch, int n, int w, int d, int k, float* out, void* stream);
+
 /* ---- bf16 STORAGE variants (BASELINE.json configs[2] / configs[4]) --------------------
  * Same arithmetic as the four forward entry points above with the windowed inputs x, the
  * projected features xlin and the aggregate z held in bfloat16 IN HBM (uint16_t = the raw

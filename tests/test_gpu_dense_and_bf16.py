@@ -22,7 +22,8 @@ from test_gpu_forward_parity import build_model, random_params
 pytestmark = pytest.mark.gpu
 
 SHAPES = [dict(b=16, n=127, w=15, k=30), dict(b=64, n=27, w=5, k=5), dict(b=8, n=64, w=15, k=63),
-          dict(b=5, n=100, w=30, k=40), dict(b=3, n=33, w=12, k=1), dict(b=700, n=51, w=15, k=15)]
+          dict(b=5, n=100, w=30, k=40), dict(b=3, n=33, w=12, k=1), dict(b=700, n=51, w=15, k=15),
+          dict(b=9, n=60, w=32, k=20), dict(b=4, n=127, w=17, k=63)]
 IDS = ["b{b}_n{n}_w{w}_k{k}".format(**s) for s in SHAPES]
 
 
@@ -43,12 +44,15 @@ def bf16_ulp(t):
     return torch.exp2(torch.floor(torch.log2(t.abs().clamp_min(1e-30))) - 7)
 
 
-def assert_bf16_stored(got, want, name):
+def assert_bf16_stored(got, want, name, fp32_floor=0.0):
+    """`fp32_floor`: absolute error the fp32 computation behind the stored value may carry (a sum whose terms
+    cancel has an error set by its TERMS, which can exceed one ulp of a small result)."""
     got, want = got.float().cpu().double(), want.double()
     diff = (got - want).abs()
     bad = diff > 0
     assert bad.double().mean() <= 2e-3, f"{name}: {bad.double().mean():.2e} of the stored bf16 values differ"
-    assert bool((diff[bad] <= 1.01 * bf16_ulp(want[bad])).all()), f"{name}: a stored value is off by more than one bf16 ulp"
+    allowed = torch.clamp_min(1.01 * bf16_ulp(want[bad]), fp32_floor)
+    assert bool((diff[bad] <= allowed).all()), f"{name}: a stored value is off by more than one bf16 ulp"
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)
@@ -76,9 +80,9 @@ def test_dense_staged_kernels_fp32_against_float64_oracle(shape, gpu_device):
 
 
 @pytest.mark.parametrize("shape", SHAPES[:3], ids=IDS[:3])
-def test_dense_kernels_are_deterministic_and_alpha_is_a_pure_side_output(shape, gpu_device):
-    """Same launch twice = same bits; asking for the attention weights does not change z; the fused kernel
-    gives the same bits for a window whatever launch it is part of."""
+def test_dense_kernels_are_deterministic_and_alpha_does_not_change_z(shape, gpu_device):
+    """Same launch twice = same bits; asking for the attention weights does not change z (to rounding);
+    the fused kernel gives the same bits for a window whatever launch it is part of."""
     from gdn_amd import ops
     model, _p, x = setup(shape, gpu_device)
     c = model._constants()
@@ -91,11 +95,41 @@ def test_dense_kernels_are_deterministic_and_alpha_is_a_pure_side_output(shape, 
     z1, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=False)
     z2, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, shape["b"], want_alpha=True)
     assert torch.equal(z0, z1)
-    assert torch.equal(z0, z2)
+    # the two variants are separate instantiations (the compiler picks packed or scalar conversions): equal to
+    # the last few bits, not bit for bit.  (An earlier build, with the 16-bit split written as inline asm,
+    # failed here by 3e-5 in ONE target row of ONE window: hipcc pads no hazards around asm.)
+    np.testing.assert_allclose(z0.cpu().numpy(), z2.cpu().numpy(), atol=3e-7, rtol=0)
     with torch.no_grad():
         o0, o1 = model(xd, None), model(xd, None)
         o2 = model(xd[1:3].contiguous(), None)
     assert torch.equal(o0, o1) and torch.equal(o0[1:3], o2)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_planned_launch_equals_the_plain_entry_point(bf16, gpu_device):
+    """gdn_forward_fused_plan (constants precomputed by gdn_fused_plan_build, what GDN.forward uses) against
+    gdn_forward_fused / gdn_forward_fused_bf16 (constants computed in every workgroup's prologue): same bits;
+    and the plan follows the parameters (rebuilt after an update)."""
+    from gdn_amd import ops
+    shape = dict(b=300, n=127, w=15, k=30)
+    model, _p, x = setup(shape, gpu_device)
+    xd = (x.bfloat16() if bf16 else x).to(gpu_device)
+    c = model._constants()
+    gnn, lin = model.gnn_layers[0].gnn, model.out_layer.mlp[0]
+    with torch.no_grad():
+        planned = model(xd, None)
+    assert c.plans[bf16] is not None
+    plain = ops.forward_fused(xd, gnn.lin.weight, c.terms, c.graph, gnn.bias, model.embedding.weight, c.bn1, c.bn2,
+                              lin.weight, lin.bias)
+    assert torch.equal(planned, plain)
+    with torch.no_grad():
+        gnn.lin.weight.mul_(1.25)                      # version bump -> constants and plan are rebuilt
+        again = model(xd, None)
+    assert not torch.equal(again, planned)
+    c2 = model._constants()
+    plain2 = ops.forward_fused(xd, gnn.lin.weight, c2.terms, c2.graph, gnn.bias, model.embedding.weight, c2.bn1,
+                               c2.bn2, lin.weight, lin.bias)
+    assert torch.equal(again, plain2)
 
 
 def test_valu_and_dense_fused_paths_agree(gpu_device):
@@ -167,7 +201,8 @@ def test_bf16_storage_staged_pipeline(shape, gpu_device):
     np.testing.assert_allclose(layer.att_weight_1.cpu().double().numpy(), ref["att_weight_1"].numpy(), atol=2e-6, rtol=0)
     a64 = alpha.cpu().double().view(b, n, -1)
     want_z = (a64.unsqueeze(-1) * xl[:, nbr]).sum(2) + p64["gnn_layers.0.gnn.bias"]
-    assert_bf16_stored(z, gdn_oracle.round_bf16(want_z).view(b * n, d), "z")
+    # alpha enters the product as two bf16 terms (2^-17 relative): 1e-5 of the largest feature
+    assert_bf16_stored(z, gdn_oracle.round_bf16(want_z).view(b * n, d), "z", fp32_floor=1e-5 * float(xl.abs().max()))
     out, _ = ops.head_fwd(z, model.embedding.weight, c.bn1, c.bn2, lin.weight, lin.bias, shape["b"])
     np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4, rtol=0)
 
