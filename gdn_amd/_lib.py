@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -33,6 +33,10 @@ SIGNATURES = {
     "gdn_mse_loss_grad": [_p, _p, ctypes.c_longlong, _p, _p, _p, _p],
     "gdn_forward_fused": [_p] * 11 + [_c_int] * 5 + [_p, _p],
     "gdn_forward_fused_series": [_p, _c_int, _c_int] + [_p] * 10 + [_c_int] * 5 + [_p, _p],
+    "gdn_mlp_plan_bytes": [_c_int] * 3,
+    "gdn_mlp_plan_layer": [_p] * 6 + [_c_float] + [_c_int] * 4 + [_p, _p],
+    "gdn_mlp_plan_out": [_p, _p] + [_c_int] * 3 + [_p, _p],
+    "gdn_mlp_fwd": [_p, _p] + [_c_int] * 4 + [_p, _p],
     "gdn_fused_plan_bytes": [_c_int] * 5,
     "gdn_fused_plan_build": [_p] * 10 + [_c_int] * 5 + [_p, _p],
     "gdn_forward_fused_plan": [_p, _p] + [_c_int] * 6 + [_p, _p],

@@ -193,7 +193,7 @@ class OutLayer(nn.Module):
 
 
 class _EvalConstants:
-    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans")
+    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans", "mlp")
 
 
 class GDN(nn.Module):
@@ -273,6 +273,7 @@ class GDN(nn.Module):
         c.bn1 = c.bn2 = None
         c.fused_args = None
         c.plans = {}                 # bf16_storage -> plan tensor (or None: shape not on the matrix-core path)
+        c.mlp = False                # eval-mode OutLayer MLP plan: False = not built yet, None = unsupported
         if not self.training:
             c.bn1 = ops.bn_fold(self.gnn_layers[0].bn)
             c.bn2 = ops.bn_fold(self.bn_outlayer_in)
@@ -348,7 +349,11 @@ class GDN(nn.Module):
             zero_w = torch.zeros((emb.shape[1],), device=x.device)
             zero_b = torch.zeros((1,), device=x.device)
             _, h2 = ops.head_fwd(z, emb, c.bn1, c.bn2, zero_w, zero_b, batch, want_h2=True)
-            with torch.no_grad():
+            if c.mlp is False:
+                c.mlp = ops.mlp_plan(self.out_layer, emb.shape[1])
+            if c.mlp is not None:                                           # GDN.py:183 on the matrix cores
+                return ops.mlp_fwd(h2, c.mlp).view(batch, node_num)
+            with torch.no_grad():       # hidden > 256: outside gdn_mlp_fwd's register budget, library GEMMs
                 out = self.out_layer(h2.view(batch, node_num, -1))
             return out.view(-1, node_num)
 

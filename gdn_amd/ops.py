@@ -150,6 +150,42 @@ def head_fwd(z, emb, bn1_affine, bn2_affine, out_w, out_b, batch: int, want_h2: 
     return out, h2
 
 
+def mlp_plan(out_layer, d_in: int):
+    """Plan of the eval-mode OutLayer MLP (include/gdn_hip.h "OutLayer MLP"): (plan, hidden, layers), or None
+    when the configuration is outside what gdn_mlp_fwd takes (hidden > 256)."""
+    mods = list(out_layer.mlp)
+    linears = [m for m in mods if isinstance(m, torch.nn.Linear)]
+    bns = [m for m in mods if isinstance(m, torch.nn.BatchNorm1d)]
+    layers = len(linears)
+    if layers < 2 or any(not b.track_running_stats or not b.affine for b in bns):
+        return None
+    hidden = linears[0].out_features
+    nbytes = _lib.load().gdn_mlp_plan_bytes(d_in, hidden, layers)
+    if nbytes == 0:
+        return None
+    dev = linears[0].weight.device
+    plan = torch.empty(((nbytes + 3) // 4,), dtype=torch.int32, device=dev)
+    for i, (lin, bn) in enumerate(zip(linears[:-1], bns)):
+        _lib.call("gdn_mlp_plan_layer", _ptr(_chk(lin.weight.detach())), _ptr(_chk(lin.bias.detach())),
+                  _ptr(_chk(bn.weight.detach())), _ptr(_chk(bn.bias.detach())), _ptr(_chk(bn.running_mean)),
+                  _ptr(_chk(bn.running_var)), float(bn.eps), d_in, hidden, layers, i, _ptr(plan), _stream())
+    last = linears[-1]
+    _lib.call("gdn_mlp_plan_out", _ptr(_chk(last.weight.detach().reshape(-1))), _ptr(_chk(last.bias.detach().reshape(-1))),
+              d_in, hidden, layers, _ptr(plan), _stream())
+    return plan, hidden, layers
+
+
+def mlp_fwd(h2, plan_info, out: torch.Tensor | None = None):
+    """h2[rows, d] -> out[rows]: OutLayer.forward (models/GDN.py:45-56) in eval mode."""
+    plan, hidden, layers = plan_info
+    h2 = _chk(h2, name="h2")
+    rows, d_in = h2.shape
+    if out is None:
+        out = torch.empty((rows,), dtype=torch.float32, device=h2.device)
+    _lib.call("gdn_mlp_fwd", _ptr(h2), _ptr(plan), rows, d_in, hidden, layers, _ptr(out), _stream())
+    return out
+
+
 def _bn_running(bn):
     """(momentum, running_mean, running_var, num_batches_tracked) pointers for the train-mode head."""
     if not bn.track_running_stats or bn.running_mean is None:

@@ -43,7 +43,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 10
+#define GDN_ABI_VERSION 11
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -110,6 +110,25 @@ int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const float* s_j
 int gdn_head_fwd(const float* z, const float* emb, const float* bn1_affine,
                  const float* bn2_affine, const float* out_w, const float* out_b,
                  int batch, int n, int d, float* out, float* h2, void* stream);
+
+/* ---- OutLayer MLP, out_layer_num > 1 (models/GDN.py:27-56,:183), eval mode -------------
+ * h2[rows, d_in] (the h2 output of gdn_head_fwd) -> [Linear(K->hidden), BatchNorm1d(hidden) with
+ * running statistics, ReLU] x (layers-1) -> Linear(hidden->1) -> out[rows], one launch, on the
+ * 16-bit matrix cores with the fp32-grade two-term split (activations never leave registers).
+ * The weights enter through a PLAN (BatchNorm folded, split, reordered), built once per parameter
+ * update: gdn_mlp_plan_layer for hidden layer `layer` = 0 .. layers-2 (weight[hidden, K],
+ * K = d_in for layer 0, hidden otherwise; bias[hidden]; the BatchNorm1d behind it), then
+ * gdn_mlp_plan_out for the final Linear (weight[hidden], bias[1]).
+ * Supported: layers 2..8, hidden <= 256, d_in in {16,32,64,128}; gdn_mlp_plan_bytes returns 0
+ * otherwise.                                                                                */
+long long gdn_mlp_plan_bytes(int d_in, int hidden, int layers);
+int gdn_mlp_plan_layer(const float* weight, const float* bias, const float* bn_weight,
+                       const float* bn_bias, const float* bn_mean, const float* bn_var, float eps,
+                       int d_in, int hidden, int layers, int layer, void* plan, void* stream);
+int gdn_mlp_plan_out(const float* weight, const float* bias, int d_in, int hidden, int layers,
+                     void* plan, void* stream);
+int gdn_mlp_fwd(const float* h2, const void* plan, int rows, int d_in, int hidden, int layers,
+                float* out, void* stream);
 
 /* ---- train-mode head (out_layer_num == 1) -------------------------------------------
  * gdn_head_train_fwd: the same chain as gdn_head_fwd under model.train(): both BatchNorms

@@ -227,3 +227,34 @@ def test_bf16_storage_refuses_shapes_outside_the_matrix_core_path(gpu_device):
     model = random_params(300, 12, 20, 64, seed=1).to(gpu_device).eval()
     with pytest.raises(GdnHipError, match="UNSUPPORTED"):
         model(torch.rand((2, 300, 12), device=gpu_device).bfloat16(), None)
+
+
+@pytest.mark.parametrize("cfg", [dict(n=127, w=15, k=30, d=64, hidden=256, layers=2, b=9),
+                                 dict(n=40, w=10, k=8, d=64, hidden=128, layers=3, b=33),
+                                 dict(n=20, w=8, k=6, d=32, hidden=48, layers=2, b=5),
+                                 dict(n=12, w=4, k=3, d=16, hidden=24, layers=4, b=70),
+                                 dict(n=30, w=20, k=10, d=128, hidden=200, layers=3, b=6)],
+                         ids=lambda c: "n{n}_d{d}_h{hidden}_L{layers}".format(**c))
+def test_outlayer_mlp_on_the_matrix_cores(cfg, gpu_device):
+    """out_layer_num > 1 in eval mode: gdn_mlp_fwd (one launch, activations in registers, BatchNorm folded into
+    the plan) against the float64 oracle's OutLayer (models/GDN.py:27-56) — non-trivial running statistics."""
+    from gdn_amd import GDN
+    torch.manual_seed(7)
+    model = GDN([torch.zeros((2, 1), dtype=torch.long)], cfg["n"], dim=cfg["d"], out_layer_inter_dim=cfg["hidden"],
+                input_dim=cfg["w"], out_layer_num=cfg["layers"], topk=cfg["k"])
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                mod.bias.copy_(torch.rand(mod.bias.shape, generator=g) * 0.4 - 0.2)
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    x = torch.rand((cfg["b"], cfg["n"], cfg["w"]), generator=g)
+    with torch.no_grad():
+        out = model(x.to(gpu_device), None)
+    assert model._constants().mlp is not None                     # the HIP kernel ran, not the library GEMMs
+    ref = gdn_oracle.forward(f64_params(p), x.double(), cfg["k"], cfg["layers"], graph=model.learned_graph.cpu())
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-6, rtol=1e-5)

@@ -404,8 +404,10 @@ def test_graph_mode_with_even_batches_keeps_validation_fresh(gpu_device, tmp_pat
         harness.test = real_test
     assert len(seen[False]) == len(seen[True]) == 3
     assert len(set(seen[True])) == 3, "validation loss did not move: stale eval constants"
-    np.testing.assert_allclose(seen[True], seen[False], atol=2e-5, rtol=0)
-    np.testing.assert_allclose(out[True][0], out[False][0], atol=2e-5, rtol=0)
+    # (two correct runs drift apart by ~1e-5 per epoch: the zero-gradient gnn.bias random-walks by +-lr per Adam
+    # step on rounding noise, see the 2-step test; stale constants would be off by ~1e-2)
+    np.testing.assert_allclose(seen[True], seen[False], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out[True][0], out[False][0], atol=1e-4, rtol=0)
     for key, val_e in out[False][1].items():
         tol = 2e-2 if key.endswith("gnn.bias") or key.endswith("0.bn.running_mean") else 1e-4
         np.testing.assert_allclose(val_e.cpu().numpy(), out[True][1][key].cpu().numpy(), atol=tol, err_msg=key)
