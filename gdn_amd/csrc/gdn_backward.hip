@@ -445,11 +445,13 @@ __global__ __launch_bounds__(256) void gdn_terms_bwd_kernel(
     const float* __restrict__ att_em_i, const float* __restrict__ att_em_j, const float* __restrict__ emb,
     const float* __restrict__ d_a, const float* __restrict__ d_c, int n, int d, int w,
     float* __restrict__ d_lin_w, float* __restrict__ d_att_i, float* __restrict__ d_att_j,
-    float* __restrict__ d_att_em_i, float* __restrict__ d_att_em_j, float* __restrict__ d_emb) {
+    float* __restrict__ d_att_em_i, float* __restrict__ d_att_em_j, float* __restrict__ d_emb,
+    int accumulate_emb) {
   const int tid = threadIdx.x;
   for (int t = blockIdx.x * 256 + tid; t < n * d; t += gridDim.x * 256) {
     const int s = t / d, c = t - s * d;
-    d_emb[t] = fmaf(d_c[s], att_em_i[c], d_c[n + s] * att_em_j[c]);
+    const float v = fmaf(d_c[s], att_em_i[c], d_c[n + s] * att_em_j[c]);
+    d_emb[t] = accumulate_emb ? d_emb[t] + v : v;   // (+ the head's share, written there by gdn_head_train_bwd)
   }
   if (blockIdx.x != 0) return;
   __shared__ float part[4][256];
@@ -598,11 +600,11 @@ extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float*
   return gdn_launch_status();
 }
 
-extern "C" int gdn_terms_bwd(const float* lin_w, const float* att_i, const float* att_j,
+extern "C" int gdn_terms_bwd_acc(const float* lin_w, const float* att_i, const float* att_j,
                              const float* att_em_i, const float* att_em_j, const float* emb,
                              const float* d_a, const float* d_c, int n, int d, int w, float* d_lin_w,
                              float* d_att_i, float* d_att_j, float* d_att_em_i, float* d_att_em_j,
-                             float* d_emb, void* stream) {
+                             float* d_emb, int accumulate_emb, void* stream) {
   if (!lin_w || !att_i || !att_j || !att_em_i || !att_em_j || !emb || !d_a || !d_c || !d_lin_w || !d_att_i ||
       !d_att_j || !d_att_em_i || !d_att_em_j || !d_emb || n <= 0 || d <= 0 || w <= 0)
     return GDN_ERR_ARG;
@@ -611,6 +613,15 @@ extern "C" int gdn_terms_bwd(const float* lin_w, const float* att_i, const float
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(gdn_terms_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, lin_w, att_i, att_j,
                      att_em_i, att_em_j, emb, d_a, d_c, n, d, w, d_lin_w, d_att_i, d_att_j, d_att_em_i,
-                     d_att_em_j, d_emb);
+                     d_att_em_j, d_emb, accumulate_emb);
   return gdn_launch_status();
+}
+
+extern "C" int gdn_terms_bwd(const float* lin_w, const float* att_i, const float* att_j,
+                             const float* att_em_i, const float* att_em_j, const float* emb,
+                             const float* d_a, const float* d_c, int n, int d, int w, float* d_lin_w,
+                             float* d_att_i, float* d_att_j, float* d_att_em_i, float* d_att_em_j,
+                             float* d_emb, void* stream) {
+  return gdn_terms_bwd_acc(lin_w, att_i, att_j, att_em_i, att_em_j, emb, d_a, d_c, n, d, w, d_lin_w, d_att_i, d_att_j,
+                           d_att_em_i, d_att_em_j, d_emb, 0, stream);
 }

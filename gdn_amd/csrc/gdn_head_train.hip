@@ -38,10 +38,25 @@ struct RunningStats {   // BatchNorm buffers updated by the forward (any pointer
   float mom1, mom2;
 };
 
+// Counter-based dropout draw (models/GDN.py:114,182 nn.Dropout): element e of step t is kept iff
+// mix32(e, seed, t) >= p * 2^32.  Stateless, so the forward pass and the three backward passes of a step
+// regenerate the same mask from (seed, step) instead of reading one from HBM; the step counter lives in
+// device memory (the optimizer increments it), so a replayed HIP graph draws a fresh mask every replay.
+// Not torch's Philox stream: parity tests inject an explicit mask instead.
+__device__ __forceinline__ unsigned gdn_mix32(unsigned e, unsigned k0, unsigned k1) {
+  unsigned x = e * 0x9E3779B1u + k0;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x += k1; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+
 struct HeadArgs {
   const float *z, *emb, *g1, *b1, *g2, *b2, *w, *bo, *mask, *d_out;
   const uint8_t* keep;   // alternative to `mask`: 1 = kept, 0 = dropped, value = keep * keep_scale
   float keep_scale;
+  const long long* rng;  // third alternative: {seed, step} in device memory -> the mask is DRAWN here (no tensor)
+  unsigned rng_threshold;   // element dropped when its 32-bit hash < threshold (= p * 2^32)
   RunningStats run;
   const double* fstats;  // [REPL][4][d]: sum z, sum z^2, sum h1, sum h1^2
   double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
@@ -178,6 +193,12 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
   double acc_s = 0.0;
   const float bias_o = (MODE == H_OUT) ? a.bo[0] : 0.f;
+  unsigned rng_k0 = 0, rng_k1 = 0;
+  if (MODE >= H_OUT && a.rng) {
+    const unsigned long long seed = (unsigned long long)a.rng[0], step = (unsigned long long)a.rng[1];
+    rng_k0 = (unsigned)seed ^ (unsigned)(step * 0x9E3779B97F4A7C15ull >> 32);
+    rng_k1 = (unsigned)(seed >> 32) + (unsigned)step * 0x7F4A7C15u;
+  }
   float e[4] = {0.f, 0.f, 0.f, 0.f};
   if (MODE >= H_STAT2 && live) ld4(a.emb + (size_t)n * D + c0, e);
 
@@ -196,6 +217,10 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
           const uchar4 kb = *reinterpret_cast<const uchar4*>(a.keep + row * D + c0);
           mq[u][0] = kb.x * a.keep_scale; mq[u][1] = kb.y * a.keep_scale;
           mq[u][2] = kb.z * a.keep_scale; mq[u][3] = kb.w * a.keep_scale;
+        } else if (MODE >= H_OUT && a.rng) {            // drawn in place: no mask traffic at all
+          const unsigned e0 = (unsigned)(row * D + c0);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) mq[u][v] = gdn_mix32(e0 + v, rng_k0, rng_k1) >= a.rng_threshold ? a.keep_scale : 0.f;
         }
         goq[u] = MODE >= H_BWD2 ? a.d_out[row] : 0.f;
       }
@@ -433,9 +458,15 @@ extern "C" long long gdn_head_train_workspace_bytes(int n, int d) {
          (long long)GDN_HEAD_EMB_PARTS * n * d * (long long)sizeof(float);
 }
 
-extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+static unsigned drop_threshold(float p_drop) {
+  const double t = (double)p_drop * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+}
+
+static int head_train_fwd_impl(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
                                   const float* bn2_w, const float* bn2_b, const float* lin_w,
-                                  const float* lin_b, const float* mask, const uint8_t* keep, float keep_scale, int batch, int n,
+                                  const float* lin_b, const float* mask, const uint8_t* keep, float keep_scale,
+                                  const long long* rng, float p_drop, int batch, int n,
                                   int d, float eps1,
                                   float eps2, float momentum1, float momentum2, float* running_mean1,
                                   float* running_var1, long long* batches1, float* running_mean2,
@@ -449,6 +480,9 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
   HeadArgs a = {};
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = lin_b;
   a.mask = mask; a.keep = mask ? nullptr : keep; a.keep_scale = keep_scale;
+  if (!mask && !keep && rng && p_drop > 0.f) {
+    a.rng = rng; a.rng_threshold = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
+  }
   a.fstats = stats; a.acc = stats; a.out = out; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
   a.run = {running_mean1, running_var1, running_mean2, running_var2, batches1, batches2, momentum1, momentum2};
@@ -470,9 +504,36 @@ extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float*
   return gdn_launch_status();
 }
 
-extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, const float* bn1_w,
+extern "C" int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                                  const float* bn2_w, const float* bn2_b, const float* lin_w,
+                                  const float* lin_b, const float* mask, const uint8_t* keep, float keep_scale, int batch, int n,
+                                  int d, float eps1,
+                                  float eps2, float momentum1, float momentum2, float* running_mean1,
+                                  float* running_var1, long long* batches1, float* running_mean2,
+                                  float* running_var2, long long* batches2, double* stats, float* out,
+                                  void* stream) {
+  return head_train_fwd_impl(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, lin_b, mask, keep, keep_scale, nullptr, 0.f,
+                             batch, n, d, eps1, eps2, momentum1, momentum2, running_mean1, running_var1, batches1,
+                             running_mean2, running_var2, batches2, stats, out, stream);
+}
+
+extern "C" int gdn_head_train_fwd_rng(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                                      const float* bn2_w, const float* bn2_b, const float* lin_w,
+                                      const float* lin_b, const long long* rng_seed_step, float p_drop, int batch,
+                                      int n, int d, float eps1, float eps2, float momentum1, float momentum2,
+                                      float* running_mean1, float* running_var1, long long* batches1,
+                                      float* running_mean2, float* running_var2, long long* batches2,
+                                      double* stats, float* out, void* stream) {
+  if (!rng_seed_step || p_drop < 0.f || p_drop >= 1.f) return GDN_ERR_ARG;
+  return head_train_fwd_impl(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, lin_b, nullptr, nullptr, 1.f, rng_seed_step,
+                             p_drop, batch, n, d, eps1, eps2, momentum1, momentum2, running_mean1, running_var1,
+                             batches1, running_mean2, running_var2, batches2, stats, out, stream);
+}
+
+static int head_train_bwd_impl(const float* d_out, const float* z, const float* emb, const float* bn1_w,
                                   const float* bn1_b, const float* bn2_w, const float* bn2_b,
                                   const float* lin_w, const float* mask, const uint8_t* keep, float keep_scale,
+                                  const long long* rng, float p_drop,
                                   const double* stats, int batch,
                                   int n, int d, float eps1, float eps2, double* workspace, float* d_z,
                                   float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
@@ -486,6 +547,9 @@ extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const floa
   HeadArgs a = {};
   a.z = z; a.emb = emb; a.g1 = bn1_w; a.b1 = bn1_b; a.g2 = bn2_w; a.b2 = bn2_b; a.w = lin_w; a.bo = nullptr;
   a.mask = mask; a.keep = mask ? nullptr : keep; a.keep_scale = keep_scale;
+  if (!mask && !keep && rng && p_drop > 0.f) {
+    a.rng = rng; a.rng_threshold = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
+  }
   a.d_out = d_out; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
   const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
@@ -508,5 +572,81 @@ extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const floa
   const int chunks = (n + 256 / (d / 4) - 1) / (256 / (d / 4));
   hipLaunchKernelGGL(gdn_head_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace,
                      a.demb_part, head_parts(batch, chunks, H_BWD1), n, d, d_bn1_w, d_bn1_b, d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, d_emb);
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, const float* bn1_w,
+                                  const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                                  const float* lin_w, const float* mask, const uint8_t* keep, float keep_scale,
+                                  const double* stats, int batch,
+                                  int n, int d, float eps1, float eps2, double* workspace, float* d_z,
+                                  float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
+                                  float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream) {
+  return head_train_bwd_impl(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, mask, keep, keep_scale, nullptr, 0.f,
+                             stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b, d_bn2_w,
+                             d_bn2_b, d_lin_w, d_lin_b, stream);
+}
+
+extern "C" int gdn_head_train_bwd_rng(const float* d_out, const float* z, const float* emb, const float* bn1_w,
+                                      const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                                      const float* lin_w, const long long* rng_seed_step, float p_drop,
+                                      const double* stats, int batch, int n, int d, float eps1, float eps2,
+                                      double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
+                                      float* d_bn2_w, float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream) {
+  if (!rng_seed_step || p_drop < 0.f || p_drop >= 1.f) return GDN_ERR_ARG;
+  return head_train_bwd_impl(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, nullptr, nullptr, 1.f, rng_seed_step,
+                             p_drop, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b,
+                             d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, stream);
+}
+
+// ---- Adam over ONE flat parameter buffer (reference train.py:31,73: torch.optim.Adam(lr, weight_decay)) ----
+// p, g, m, v: flat fp32 [count] (every parameter of the model back to back; the gradients are written
+// straight into g by the backward kernels, and with several ranks g is what the single all-reduce sums:
+// grad_scale = 1 / ranks turns the sum into the mean).  step[0] = number of steps taken so far, in device
+// memory, incremented here — it is also the counter of the in-kernel dropout draw.  The update is
+// torch.optim.Adam's (amsgrad off, maximize off), in its single-tensor order of operations:
+//   g += wd p;  m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;
+//   p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// One workgroup (the state is a few 10^4 values): its thread 0 alone touches the counter.
+__global__ __launch_bounds__(1024) void gdn_adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        long long* __restrict__ step, int count, double lr_d,
+                                                        double beta1_d, double beta2_d, double eps_d, double wd_d,
+                                                        double grad_scale_d, int zero_from, int zero_count) {
+  // scalars arrive as the Python floats torch's optimizer holds (double) and are rounded to fp32 where torch
+  // rounds them: 1 - beta in double first (1 - 0.999f is 4.7e-5 off 0.001)
+  const long long t = step[0] + 1;
+  const double bc1 = 1.0 - pow(beta1_d, (double)t);
+  const double bc2 = 1.0 - pow(beta2_d, (double)t);
+  const float step_size = (float)(lr_d / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float beta2 = (float)beta2_d, omb1 = (float)(1.0 - beta1_d), omb2 = (float)(1.0 - beta2_d);
+  const float eps = (float)eps_d, wd = (float)wd_d, grad_scale = (float)grad_scale_d;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const float pi = p[i];
+    float gi = g[i] * grad_scale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = m[i];
+    mi = mi + (gi - mi) * omb1;
+    const float vi = fmaf(v[i], beta2, omb2 * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    // gradient slots the next backward ACCUMULATES into (atomics) are handed back cleared
+    if (i >= zero_from && i < zero_from + zero_count) g[i] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) step[0] = t;
+}
+
+extern "C" int gdn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                             long long* step, int count, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, double grad_scale, int zero_from, int zero_count, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step || count <= 0 || zero_from < 0 || zero_count < 0)
+    return GDN_ERR_ARG;
+  hipLaunchKernelGGL(gdn_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, step, count, lr, beta1, beta2, eps, weight_decay, grad_scale, zero_from,
+                     zero_count);
   return gdn_launch_status();
 }

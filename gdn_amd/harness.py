@@ -465,9 +465,11 @@ class SeriesEvaluator:
 
 
 # --------------------------------------------------------------------------- graphed train step
-class GraphedTrainStep:
+class AutogradTrainStep:
     """One optimisation step of the reference's train() (train.py:52-66: zero_grad, forward, MSE,
-    backward, Adam) captured once in a HIP graph and replayed per minibatch.
+    backward, Adam) captured once in a HIP graph and replayed per minibatch — the form that goes through
+    torch autograd and torch.optim.Adam(fused=True): used when `NativeTrainStep` does not apply
+    (out_layer_num > 1, a custom `model.dp` module).
 
     At the reference's batch sizes a step is ~30 launches of a few microseconds each, so issuing
     them from Python costs more than running them; a replayed graph removes that.  The graph
@@ -583,3 +585,240 @@ class GraphedTrainStep:
         # attention terms, BatchNorm folds) must be dropped here or eval after training serves stale ones
         self.model.invalidate_constants()
         return self.loss
+
+
+class _FlatAdam:
+    """What `train()` needs from an optimizer for the batches that do not go through the captured step (the
+    ragged last batch of an epoch): zero_grad() / step() over the SAME flat Adam state as the native step."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.owner.params:
+            p.grad = None
+
+    def step(self):
+        o = self.owner
+        with torch.no_grad():
+            for p, (off, cnt) in zip(o.params, o.slices):
+                if p.grad is not None:
+                    o.flat_g[off:off + cnt].copy_(p.grad.reshape(-1))
+                else:
+                    o.flat_g[off:off + cnt].zero_()
+        o._adam()
+        o.model.invalidate_constants()
+
+
+class NativeTrainStep:
+    """the training step of train.py:63-79 with nothing but this library's kernels between the
+    input batch and the updated parameters — no autograd graph, no torch optimizer, no mask tensor.
+
+      * every parameter is a VIEW into one flat fp32 buffer; gradients, Adam's exp_avg / exp_avg_sq are flat
+        buffers of the same layout;
+      * forward: sensor graph + folded attention terms (they depend on the parameters of this step) ->
+        projection -> attention/aggregate (keeps alpha) -> train-mode head with the dropout mask DRAWN in the
+        kernels from (seed, step) -> fused MSE loss + its gradient;
+      * backward: every kernel writes its parameter gradients straight into their slots of the flat gradient
+        buffer (the two shares of the embedding gradient meet in one slot: gdn_terms_bwd_acc), so there is
+        no zero_grad, no packing and no unpacking;
+      * with several ranks the flat gradient buffer IS the bucket of the one all-reduce (sum; the 1/ranks is
+        folded into the optimizer kernel);
+      * gdn_adam_step: one launch over the flat buffers, torch.optim.Adam's update.
+
+    The launches of a step are captured once in a HIP graph (two graphs around the all-reduce with >1 rank).
+    `x` / `y` are the static input buffers; `loss` a device scalar.  BatchNorm uses per-rank batch
+    statistics (standard DDP)."""
+
+    BETAS, EPS = (0.9, 0.999), 1e-8
+
+    @staticmethod
+    def applicable(model) -> bool:
+        import torch.nn as nn
+        return (model.out_layer_num == 1 and type(model.dp) is nn.Dropout and model._hip_train_head_ok()
+                and model.injected_graph is None and next(model.parameters()).is_cuda)
+
+    def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
+                 split: bool | None = None, seed: int | None = None):
+        from . import _lib
+        self._lib = _lib
+        self.model = model.train()
+        dev = next(model.parameters()).device
+        self.lr, self.wd = float(lr), float(weight_decay)
+        self.params = list(model.parameters())
+        # flat parameter buffer; every slot starts on a 16-byte boundary (the kernels read rows as float4)
+        self.slices, total = [], 0
+        for p in self.params:
+            self.slices.append((total, p.numel()))
+            total += (p.numel() + 3) & ~3
+        self.count = total
+        self.flat_p = torch.zeros((total,), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, (off, cnt) in zip(self.params, self.slices):
+                self.flat_p[off:off + cnt].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[off:off + cnt].view(p.shape)
+        model.invalidate_constants()
+        model._key_tensors = None
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # torch's seeded generator picks the stream
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=dev)     # {dropout seed, steps taken}
+        self.optimizer = _FlatAdam(self)
+
+        gnn, layer = model.gnn_layers[0].gnn, model.gnn_layers[0]
+        n, d = model.embedding.weight.shape
+        w, k = gnn.lin.weight.shape[1], model.topk
+        self.n, self.d, self.w, self.k, self.batch = n, d, w, k, batch
+        lib = _lib.load()
+        pitch = ops.nbr_pitch(k)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = torch.zeros((batch, n, w), **f32)
+        self.y = torch.zeros((batch, n), **f32)
+        self.loss = torch.zeros((), **f32)
+        bn_rows = batch * n
+        self.ws = dict(
+            topk=torch.empty((n, k), dtype=torch.int64, device=dev),
+            nbr=torch.empty((n, pitch), dtype=torch.uint16, device=dev),
+            deg=torch.empty((n,), dtype=torch.int32, device=dev),
+            rent=torch.empty((n, (n + 15) & ~15), dtype=torch.int32, device=dev),
+            rlen=torch.empty((n,), dtype=torch.int32, device=dev),
+            terms=torch.empty((128 + 2 * n,), **f32),
+            xlin=torch.empty((bn_rows, d), **f32), s_i=torch.empty((bn_rows,), **f32), s_j=torch.empty((bn_rows,), **f32),
+            z=torch.empty((bn_rows, d), **f32), alpha=torch.empty((bn_rows, pitch), **f32),
+            out=torch.empty((batch, n), **f32), d_out=torch.empty((batch, n), **f32),
+            stats=torch.empty((lib.gdn_head_train_stats_bytes(d) // 8,), dtype=torch.float64, device=dev),
+            head_ws=torch.empty((lib.gdn_head_train_workspace_bytes(n, d) // 8,), dtype=torch.float64, device=dev),
+            d_z=torch.empty((bn_rows, d), **f32), d_xlin=torch.empty((bn_rows, d), **f32),
+            d_si=torch.empty((bn_rows,), **f32), d_sj=torch.empty((bn_rows,), **f32),
+            proj_ws=torch.empty((lib.gdn_project_bwd_workspace_bytes(n, w, d) // 4,), **f32),
+            d_a=torch.empty((128,), **f32), d_c=torch.empty((2 * n,), **f32),
+            mse_ws=ops.mse_workspace(dev),
+        )
+        self.use_graph = use_graph
+        self._graphs = None
+        self._split = world()[1] > 1 if split is None else bool(split)
+        name_of = {id(p): name for name, p in model.named_parameters()}
+        self._off = {name_of[id(p)]: off for p, (off, _c) in zip(self.params, self.slices)}
+        self._bias_slot = (self._off["gnn_layers.0.gnn.bias"], d)
+        self._layer, self._gnn = layer, gnn
+
+    # pointers -------------------------------------------------------------------------------------------------
+    def _pp(self, name):
+        return self.flat_p.data_ptr() + 4 * self._off[name]
+
+    def _gp(self, name):
+        return self.flat_g.data_ptr() + 4 * self._off[name]
+
+    def _bn_run(self, bn):
+        if not bn.track_running_stats or bn.running_mean is None:
+            return 0.0, None, None, None
+        return float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+
+    # the two halves of a step ---------------------------------------------------------------------------------
+    def _forward_backward(self):
+        call, ws, m = self._lib.call, self.ws, self.model
+        st = torch.cuda.current_stream().cuda_stream
+        n, d, w, k, b = self.n, self.d, self.w, self.k, self.batch
+        P, G = self._pp, self._gp
+        g = "gnn_layers.0.gnn."
+        bn1, bn2 = self._layer.bn, m.bn_outlayer_in
+        p_drop = float(m.dp.p) if m.dp.training else 0.0
+        rng = self.state.data_ptr()
+        pt = {key: t.data_ptr() for key, t in ws.items()}
+        # graph + folded attention terms of THIS step's parameters (models/GDN.py:145-165, graph_layer.py:94-104)
+        call("gdn_topk_graph", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], None, st)
+        call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], st)
+        call("gdn_node_terms", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
+             P("embedding.weight"), n, d, w, pt["terms"], st)
+        call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
+             pt["s_j"], st)
+        call("gdn_attn_aggregate_fwd", pt["xlin"], pt["s_i"], pt["s_j"], pt["nbr"], pt["deg"], P(g + "bias"), b, n, d, k,
+             pt["z"], pt["alpha"], st)
+        m1, rm1, rv1, nb1 = self._bn_run(bn1)
+        m2, rm2, rv2, nb2 = self._bn_run(bn2)
+        head = (P("gnn_layers.0.bn.weight"), P("gnn_layers.0.bn.bias"), P("bn_outlayer_in.weight"), P("bn_outlayer_in.bias"),
+                P("out_layer.mlp.0.weight"))
+        call("gdn_head_train_fwd_rng", pt["z"], P("embedding.weight"), *head, P("out_layer.mlp.0.bias"), rng, p_drop, b, n, d,
+             float(bn1.eps), float(bn2.eps), m1, m2, rm1, rv1, nb1, rm2, rv2, nb2, pt["stats"], pt["out"], st)
+        call("gdn_mse_loss_grad", pt["out"], self.y.data_ptr(), b * n, pt["mse_ws"], self.loss.data_ptr(), pt["d_out"], st)
+        # backward: gradients land in their slots of flat_g
+        call("gdn_head_train_bwd_rng", pt["d_out"], pt["z"], P("embedding.weight"), *head, rng, p_drop, pt["stats"], b, n, d,
+             float(bn1.eps), float(bn2.eps), pt["head_ws"], pt["d_z"], G("embedding.weight"), G("gnn_layers.0.bn.weight"),
+             G("gnn_layers.0.bn.bias"), G("bn_outlayer_in.weight"), G("bn_outlayer_in.bias"), G("out_layer.mlp.0.weight"),
+             G("out_layer.mlp.0.bias"), st)
+        call("gdn_attn_aggregate_bwd", pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
+             pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), st)     # slot cleared by Adam
+        call("gdn_project_bwd", self.x.data_ptr(), pt["d_xlin"], pt["d_si"], pt["d_sj"], b, n, w, d, pt["proj_ws"],
+             G(g + "lin.weight"), pt["d_a"], pt["d_c"], st)
+        call("gdn_terms_bwd_acc", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
+             P("embedding.weight"), pt["d_a"], pt["d_c"], n, d, w, G(g + "lin.weight"), G(g + "att_i"), G(g + "att_j"),
+             G(g + "att_em_i"), G(g + "att_em_j"), G("embedding.weight"), 1, st)
+
+    def _all_reduce(self):
+        if world()[1] > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+
+    def _adam(self):
+        self._lib.call("gdn_adam_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                       self.exp_avg_sq.data_ptr(), self.state.data_ptr() + 8, self.count, self.lr, self.BETAS[0],
+                       self.BETAS[1], self.EPS, self.wd, 1.0 / max(1, world()[1]), self._bias_slot[0], self._bias_slot[1],
+                       torch.cuda.current_stream().cuda_stream)
+
+    def _capture(self):
+        """Warm up (lazy attribute / occupancy queries) and capture; the warm-up steps are undone: capturing must
+        not train the model."""
+        tensors = [self.flat_p, self.exp_avg, self.exp_avg_sq, self.state] + list(self.model.buffers())
+        saved = [t.detach().clone() for t in tensors]
+        for _ in range(2):
+            self._forward_backward()
+            self._all_reduce()
+            self._adam()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, s_ in zip(tensors, saved):
+                t.copy_(s_)
+            self.flat_g.zero_()
+        torch.cuda.synchronize()
+        graphs = []
+        if self._split:
+            for fn in (self._forward_backward, self._adam):
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    fn()
+                graphs.append(g_)
+        else:
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                self._forward_backward()
+                self._adam()
+            graphs.append(g_)
+        self._graphs = graphs
+
+    def step(self):
+        if not self.use_graph:
+            self._forward_backward()
+            if self._split:
+                self._all_reduce()
+            self._adam()
+        else:
+            if self._graphs is None:
+                self._capture()
+            self._graphs[0].replay()
+            if self._split:
+                self._all_reduce()
+                self._graphs[1].replay()
+        self.model.invalidate_constants()       # parameters moved under the model's cached eval constants
+        return self.loss
+
+
+def GraphedTrainStep(model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
+                     split: bool | None = None, native: bool | None = None):
+    """The captured training step: `NativeTrainStep` when the model allows it (out_layer_num == 1, plain
+    nn.Dropout), else `AutogradTrainStep`.  `native=False` forces the autograd form."""
+    if native is None:
+        native = NativeTrainStep.applicable(model)
+    if native:
+        return NativeTrainStep(model, batch, lr=lr, weight_decay=weight_decay, use_graph=use_graph, split=split)
+    return AutogradTrainStep(model, batch, lr=lr, weight_decay=weight_decay, use_graph=use_graph, split=split)

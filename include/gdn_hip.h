@@ -43,7 +43,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 11
+#define GDN_ABI_VERSION 12
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -164,6 +164,36 @@ int gdn_head_train_bwd(const float* d_out, const float* z, const float* emb, con
                        int batch, int n, int d, float eps1, float eps2, double* workspace,
                        float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
                        float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);
+
+/* The same two passes with the dropout mask of models/GDN.py:114,182 DRAWN INSIDE the kernels instead of
+ * read from a tensor: element e of training step t is dropped iff mix32(e, seed, t) < p_drop * 2^32, kept
+ * values are scaled by 1/(1-p_drop).  rng_seed_step = {seed, t} (two int64 in device memory); the forward
+ * and the backward of one step must see the same pair (gdn_adam_step increments t after the backward).
+ * Stateless draw: nothing [BN,d]-sized is written or read for the mask.  It is NOT torch's Philox stream:
+ * reproducing a given torch mask needs the mask/keep arguments of the plain entry points.             */
+int gdn_head_train_fwd_rng(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                           const float* bn2_w, const float* bn2_b, const float* lin_w,
+                           const float* lin_b, const long long* rng_seed_step, float p_drop,
+                           int batch, int n, int d, float eps1, float eps2, float momentum1,
+                           float momentum2, float* running_mean1, float* running_var1,
+                           long long* batches1, float* running_mean2, float* running_var2,
+                           long long* batches2, double* stats, float* out, void* stream);
+int gdn_head_train_bwd_rng(const float* d_out, const float* z, const float* emb, const float* bn1_w,
+                           const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                           const float* lin_w, const long long* rng_seed_step, float p_drop,
+                           const double* stats, int batch, int n, int d, float eps1, float eps2,
+                           double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
+                           float* d_bn2_w, float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);
+
+/* gdn_adam_step: torch.optim.Adam(lr, betas, eps, weight_decay) of train.py:31,73 over ONE flat fp32
+ * buffer holding every parameter back to back (params / grads / exp_avg / exp_avg_sq: [count]); step[0] =
+ * steps taken so far (device memory), incremented by the call.  grads are multiplied by grad_scale first
+ * (1/ranks after a summing all-reduce).  Same update, in the same operation order, as torch's
+ * single-tensor Adam (amsgrad and maximize off).  grads[zero_from, zero_from + zero_count) is cleared
+ * after use: the slot of gnn.bias, which gdn_attn_aggregate_bwd accumulates into with atomics.          */
+int gdn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                  long long* step, int count, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double grad_scale, int zero_from, int zero_count, void* stream);
 
 /* gdn_mse_loss_grad: train.py:20-23 `F.mse_loss(out, y, reduction='mean')` and the gradient
  * autograd derives for it, d_out = 2 (out - y) / count, in one launch (fp64 accumulation,
@@ -320,6 +350,15 @@ int gdn_score_quantiles(const float* pred, const float* gt, int t, int n,
 int gdn_score_smooth_max(const float* pred, const float* gt, const double* med_iqr,
                          int t, int n, int first_tick, const float* halo_pred,
                          const float* halo_gt, double* scores, double* anomaly, void* stream);
+
+/* gdn_terms_bwd with accumulate_emb != 0: d_emb += (instead of =) — the head's share of the embedding
+ * gradient already sits in d_emb (gdn_head_train_bwd), so both land in one gradient slot without an add
+ * kernel.                                                                                              */
+int gdn_terms_bwd_acc(const float* lin_w, const float* att_i, const float* att_j,
+                      const float* att_em_i, const float* att_em_j, const float* emb,
+                      const float* d_a, const float* d_c, int n, int d, int w, float* d_lin_w,
+                      float* d_att_i, float* d_att_j, float* d_att_em_i, float* d_att_em_j,
+                      float* d_emb, int accumulate_emb, void* stream);
 
 #ifdef __cplusplus
 }

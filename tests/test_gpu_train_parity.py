@@ -443,3 +443,119 @@ def test_eval_after_replays_equals_a_fresh_model_with_the_same_state(gpu_device)
     ev2 = harness.SeriesEvaluator(fresh, x, y, batch=32, use_graph=False, streams=1)
     np.testing.assert_array_equal(after.cpu().numpy(), ev2.step().cpu().numpy())
     assert not torch.equal(before, after)
+
+
+# ------------------------------------------------------------------ native step
+def test_adam_kernel_matches_torch_adam(gpu_device):
+    """gdn_adam_step over a flat buffer against torch.optim.Adam (single-tensor form) on the same gradients,
+    with and without weight decay, over several steps; the cleared gradient slot and the step counter."""
+    from gdn_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    for wd in (0.0, 0.01):
+        count = 9729 + 3
+        p0 = torch.randn((count,), generator=g)
+        ref_p = p0.clone().to(gpu_device).requires_grad_(True)
+        opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=wd)
+        p = p0.clone().to(gpu_device)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        state = torch.zeros((1,), dtype=torch.int64, device=gpu_device)
+        for step in range(6):
+            grads = (torch.randn((count,), generator=g) * (10.0 ** (step - 3))).to(gpu_device)
+            ref_p.grad = grads.clone()
+            opt.step()
+            gbuf = grads.clone()
+            _lib.call("gdn_adam_step", p.data_ptr(), gbuf.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(), count,
+                      1e-3, 0.9, 0.999, 1e-8, wd, 1.0, 100, 64, torch.cuda.current_stream().cuda_stream)
+            assert int(state[0]) == step + 1
+            assert float(gbuf[100:164].abs().max()) == 0.0 and torch.equal(gbuf[:100], grads[:100])
+            np.testing.assert_allclose(p.cpu().numpy(), ref_p.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+        # (elements of exp_avg that cancel to ~0 carry the rounding of their large terms)
+        np.testing.assert_allclose(m.cpu().numpy(), opt.state[ref_p]["exp_avg"].cpu().numpy(), rtol=1e-6,
+                                   atol=2e-7 * float(m.abs().max()))
+        np.testing.assert_allclose(v.cpu().numpy(), opt.state[ref_p]["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-30)
+        # (1 - beta2 is formed in double like torch's Python-float arithmetic: 1 - 0.999f would be 4.7e-5 off)
+
+
+def _mix32_mask(seed, step, count, p_drop, device):
+    """torch restatement of the in-kernel dropout draw (gdn_head_train.hip: gdn_mix32)."""
+    M = 0xFFFFFFFF
+    k0 = (seed & M) ^ (((step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF) >> 32)
+    k1 = ((seed >> 32) + ((step * 0x7F4A7C15) & M)) & M
+    x = (torch.arange(count, dtype=torch.int64, device=device) * 0x9E3779B1 + k0) & M
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & M
+    x = x ^ (x >> 13)
+    x = (x + k1) & M
+    x = (x * 0xC2B2AE35) & M
+    x = x ^ (x >> 16)
+    return x >= int(p_drop * 4294967296.0)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_native_train_step_equals_the_autograd_step(p_drop, gpu_device):
+    """NativeTrainStep (no autograd, gradients straight into the flat bucket, gdn_adam_step, dropout drawn in the
+    kernels) against the autograd + torch.optim.Adam path fed THE SAME dropout masks (recomputed here from the
+    documented hash): per-step losses, gradients of the first step, parameters after 5 steps."""
+    from gdn_amd import harness
+    from test_gpu_forward_parity import random_params
+    b, n, w, k, d, steps, seed = 48, 27, 10, 8, 64, 5, 1234567890123
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand((steps, b, n, w), generator=g).to(gpu_device)
+    ys = torch.rand((steps, b, n), generator=g).to(gpu_device)
+
+    model = random_params(n, w, k, d, seed=9).to(gpu_device)
+    model.dp.p = p_drop
+    nat = harness.NativeTrainStep(model, b, use_graph=True, seed=seed)
+    assert all(p.data_ptr() >= nat.flat_p.data_ptr() and p.data_ptr() < nat.flat_p.data_ptr() + 4 * nat.count
+               for p in model.parameters())          # the parameters ARE views of the flat buffer
+
+    ref = random_params(n, w, k, d, seed=9).to(gpu_device).train()
+    masks = [(_mix32_mask(seed, t, b * n * d, p_drop, gpu_device).float() / (1.0 - p_drop)).view(b, n, d)
+             for t in range(steps)]
+    ref.dp = FixedMaskDropout(masks)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    names = [name for name, _ in ref.named_parameters()]
+    for t in range(steps):
+        nat.x.copy_(xs[t]); nat.y.copy_(ys[t])
+        loss_n = float(nat.step())
+        opt.zero_grad()
+        loss_r = torch.nn.functional.mse_loss(ref(xs[t], None), ys[t])
+        loss_r.backward()
+        if t == 0:
+            for name, prm, (off, cnt) in zip(names, ref.parameters(), nat.slices):
+                if name.endswith("gnn.bias"):
+                    continue        # cleared by the optimizer kernel after use (and its true value is 0)
+                got = nat.flat_g[off:off + cnt].view(prm.shape)
+                np.testing.assert_allclose(got.cpu().numpy(), prm.grad.cpu().numpy(), atol=2e-6, rtol=1e-4, err_msg=name)
+        opt.step()
+        assert abs(loss_n - float(loss_r.detach())) < 2e-6, (t, loss_n, float(loss_r.detach()))
+    assert int(nat.state[1]) == steps
+    for name, pa, pb in zip(names, model.parameters(), ref.parameters()):
+        tol = 6e-3 if name.endswith("gnn.bias") else 2e-5
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), atol=tol, err_msg=name)
+    if p_drop > 0:
+        kept = torch.stack(masks).ne(0).float().mean().item()
+        assert abs(kept - (1.0 - p_drop)) < 2e-3         # the draw has the right rate
+
+
+def test_native_step_state_follows_checkpoint_round_trip(gpu_device):
+    """Parameters stay ordinary module parameters: state_dict() sees the trained values and a fresh model loaded
+    from it predicts what the trained one predicts."""
+    from gdn_amd import GDN, harness
+    from test_gpu_forward_parity import random_params
+    model = random_params(27, 10, 8, 64, seed=2).to(gpu_device)
+    step = harness.GraphedTrainStep(model, 32)
+    assert isinstance(step, harness.NativeTrainStep)
+    step.x.copy_(torch.rand_like(step.x)); step.y.copy_(torch.rand_like(step.y))
+    l0 = float(step.step())
+    for _ in range(30):
+        step.step()
+    assert float(step.loss) < l0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    fresh = GDN([torch.zeros((2, 1), dtype=torch.long)], 27, dim=64, input_dim=10, topk=8)
+    fresh.load_state_dict(sd)
+    fresh = fresh.to(gpu_device).eval()
+    model.eval()
+    x = torch.rand((8, 27, 10), device=gpu_device)
+    with torch.no_grad():
+        assert torch.equal(model(x, None), fresh(x, None))
