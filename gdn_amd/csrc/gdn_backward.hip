@@ -104,13 +104,17 @@ struct BwdPlan {
 // NT threads per workgroup: 512 (8 waves, 4 per SIMD with two workgroups per CU) hides the LDS / DPP
 // latency chains of the two gather loops better than 256; BL = targets / sources a lane group
 // prefetches for before it starts computing (fewer at 512 threads: 128 VGPRs per lane).
-template <int D, int NT>
+// GLB = the two [n, pitch] tables and the lists do not fit beside the tile (large n: 512 sensors x 80
+// slots are 164 KB per table): alpha and the lists are read from global memory (L2 resident: one window's
+// worth), d_pi goes through a caller-provided [BN, pitch] workspace (written in pass 1, read in pass 2 by
+// other lanes of the SAME workgroup, a barrier in between).  Same arithmetic, same summation order.
+template <int D, int NT, bool GLB>
 __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     const BwdPlan pl, const float* __restrict__ d_z, const float* __restrict__ xlin,
     const float* __restrict__ alpha, const float* __restrict__ s_i, const float* __restrict__ s_j,
     const uint16_t* __restrict__ nbr, const uint32_t* __restrict__ rent, const int32_t* __restrict__ rlen,
     float* __restrict__ d_xlin, float* __restrict__ d_si, float* __restrict__ d_sj,
-    float* __restrict__ d_bias) {
+    float* __restrict__ d_bias, float* __restrict__ dpi_ws) {
   using G = GeoB<D>;
   constexpr int BL = 2048 / NT;
   extern __shared__ float4 smem_b4[];
@@ -118,10 +122,7 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
   float* tile = smem + pl.off_tile;    // xlin (pass 1) then d_z (pass 2); row n stays 0
   float* sj = smem + pl.off_sj;
   float* si = smem + pl.off_si;
-  float* al_t = smem + pl.off_al;      // alpha  [n, pitch]
-  float* dpi_t = smem + pl.off_dpi;    // d_alpha, then d_pi   [n, pitch]
   float* dbias = smem + pl.off_dbias;
-  uint16_t* nb_l = reinterpret_cast<uint16_t*>(smem + pl.off_nbr);   // neighbour lists [n, pitch]
   const int tid = threadIdx.x, nth = blockDim.x;
   const int grp = tid >> 4, l16 = tid & 15;
   const int slot = grp / G::NS, slice = grp % G::NS;
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     tile[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
   }
   if (tid == 0) sj[pl.n] = 0.f;
-  for (int t = tid; t < npl / 2; t += nth)   // pitch is a multiple of 16: copy the lists as u32 pairs
-    reinterpret_cast<uint32_t*>(nb_l)[t] = reinterpret_cast<const uint32_t*>(nbr)[t];
+  if constexpr (!GLB)
+    for (int t = tid; t < npl / 2; t += nth)   // pitch is a multiple of 16: copy the lists as u32 pairs
+      reinterpret_cast<uint32_t*>(smem + pl.off_nbr)[t] = reinterpret_cast<const uint32_t*>(nbr)[t];
   PackB<G::VEC> bias_acc;
 #pragma unroll
   for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] = 0.f;
@@ -145,15 +147,30 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
 
   for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
     const size_t row0 = (size_t)b * pl.n;
+    // the three per-window tables: LDS copies, or (GLB) the global arrays themselves
+    const float* al_t;            // alpha  [n, pitch]
+    float* dpi_t;                 // d_alpha, then d_pi   [n, pitch]
+    const uint16_t* nb_l;         // neighbour lists [n, pitch]
+    if constexpr (GLB) {
+      al_t = alpha + row0 * pl.pitch;
+      dpi_t = dpi_ws + row0 * pl.pitch;
+      nb_l = nbr;
+    } else {
+      al_t = smem + pl.off_al;
+      dpi_t = smem + pl.off_dpi;
+      nb_l = reinterpret_cast<const uint16_t*>(smem + pl.off_nbr);
+    }
     {   // bulk staging (many loads in flight): xlin tile, alpha table, s_i, s_j
       const float4* src = reinterpret_cast<const float4*>(xlin + row0 * D);
       float4* dst = reinterpret_cast<float4*>(tile);
 #pragma unroll 4
       for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
-      const float4* asrc = reinterpret_cast<const float4*>(alpha + row0 * pl.pitch);
-      float4* adst = reinterpret_cast<float4*>(al_t);
+      if constexpr (!GLB) {
+        const float4* asrc = reinterpret_cast<const float4*>(alpha + row0 * pl.pitch);
+        float4* adst = reinterpret_cast<float4*>(smem + pl.off_al);
 #pragma unroll 4
-      for (int t = tid; t < npl / 4; t += nth) adst[t] = asrc[t];
+        for (int t = tid; t < npl / 4; t += nth) adst[t] = asrc[t];
+      }
       for (int t = tid; t < pl.n; t += nth) {
         sj[t] = s_j[row0 + t];
         si[t] = s_i[row0 + t];
@@ -514,39 +531,59 @@ extern "C" int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n,
   return gdn_launch_status();
 }
 
-extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
-                                      const float* s_i, const float* s_j, const uint16_t* nbr,
-                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
-                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
-                                      void* stream) {
+// LDS plan of the backward: with_tables = the two [n, pitch] tables and the lists sit beside the tile
+static bool bwd_plan(int batch, int n, int d, int k, bool with_tables, BwdPlan* pl) {
+  pl->n = n; pl->d = d; pl->k = k; pl->batch = batch; pl->pitch = gdn_nbr_pitch(k); pl->rpitch = gdn_rev_pitch(n);
+  const int npad = (n + 1 + 3) & ~3;   // +1: the sentinel index n used as list padding
+  int off = 0;
+  pl->off_tile = off; off += (n + 1) * d;
+  pl->off_sj = off; off += npad;
+  pl->off_si = off; off += npad;
+  pl->off_al = off; off += with_tables ? n * pl->pitch : 0;
+  pl->off_dpi = off; off += with_tables ? n * pl->pitch : 0;
+  pl->off_dbias = off; off += d;
+  pl->off_nbr = off; off += with_tables ? n * pl->pitch / 2 : 0;   // u16 lists
+  pl->lds_bytes = off * 4;
+  return pl->lds_bytes <= 160 * 1024;
+}
+
+extern "C" long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, int d, int k) {
+  if (batch <= 0 || n <= 0 || k <= 0 || k > n || d <= 0) return 0;
+  BwdPlan pl;
+  if (bwd_plan(batch, n, d, k, true, &pl)) return 0;                   // everything fits in LDS
+  return (long long)batch * n * gdn_nbr_pitch(k) * (long long)sizeof(float);
+}
+
+extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, const float* alpha,
+                                         const float* s_i, const float* s_j, const uint16_t* nbr,
+                                         const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                         int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                         float* workspace, void* stream) {
   if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !rent || !rlen || !d_xlin || !d_si || !d_sj ||
       !d_bias || batch <= 0 || n <= 0 || k <= 0)
     return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
   BwdPlan pl;
-  pl.n = n; pl.d = d; pl.k = k; pl.batch = batch; pl.pitch = gdn_nbr_pitch(k); pl.rpitch = gdn_rev_pitch(n);
-  const int npad = (n + 1 + 3) & ~3;   // +1: the sentinel index n used as list padding
-  int off = 0;
-  pl.off_tile = off; off += (n + 1) * d;
-  pl.off_sj = off; off += npad;
-  pl.off_si = off; off += npad;
-  pl.off_al = off; off += n * pl.pitch;
-  pl.off_dpi = off; off += n * pl.pitch;
-  pl.off_dbias = off; off += d;
-  pl.off_nbr = off; off += n * pl.pitch / 2;   // u16 lists
-  pl.lds_bytes = off * 4;
-  if (pl.lds_bytes > 160 * 1024) return GDN_ERR_UNSUPPORTED;   // n*d tile + two [n,pitch] tables
+  bool glb = false;
+  if (!bwd_plan(batch, n, d, k, true, &pl)) {
+    // tables through global memory: needs the workspace, and the tile alone must still fit
+    if (!workspace || !bwd_plan(batch, n, d, k, false, &pl)) return GDN_ERR_UNSUPPORTED;
+    glb = true;
+  }
   hipStream_t st = (hipStream_t)stream;
-#define GDN_BWD_NT(DD, NT)                                                                            \
+#define GDN_BWD_NT(DD, NT, GL)                                                                        \
   {                                                                                                   \
-    const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD, NT>, NT, pl.lds_bytes, batch);            \
-    hipLaunchKernelGGL((gdn_attn_bwd_kernel<DD, NT>), dim3(grid), dim3(NT), pl.lds_bytes, st, pl, d_z, xlin, \
-                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias);                 \
+    const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD, NT, GL>, NT, pl.lds_bytes, batch);        \
+    hipLaunchKernelGGL((gdn_attn_bwd_kernel<DD, NT, GL>), dim3(grid), dim3(NT), pl.lds_bytes, st, pl, d_z, xlin, \
+                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias, workspace);      \
   }
 #define GDN_BWD(DD)                                                   \
   case DD:                                                            \
-    if (wide) GDN_BWD_NT(DD, 512) else GDN_BWD_NT(DD, 256) break;
+    if (glb) GDN_BWD_NT(DD, 512, true)                                \
+    else if (wide) GDN_BWD_NT(DD, 512, false)                         \
+    else GDN_BWD_NT(DD, 256, false)                                   \
+    break;
   const bool wide = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
   switch (d) {
     GDN_BWD(16)
@@ -557,6 +594,15 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
 #undef GDN_BWD
 #undef GDN_BWD_NT
   return gdn_launch_status();
+}
+
+extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
+                                      const float* s_i, const float* s_j, const uint16_t* nbr,
+                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                      void* stream) {
+  return gdn_attn_aggregate_bwd_ws(d_z, xlin, alpha, s_i, s_j, nbr, rent, rlen, batch, n, d, k, d_xlin, d_si,
+                                   d_sj, d_bias, nullptr, stream);
 }
 
 extern "C" long long gdn_project_bwd_workspace_bytes(int n, int w, int d) {

@@ -23,10 +23,12 @@
  * and the window's working set must fit the 160 KB of LDS of one CU:
  *   forward (staged and fused): the xlin tile (n+1)*dc*4 bytes, dc = d (d = 128: 64, two
  *     column slices) — n up to ~600 at d = 64/128, ~1000 at d = 32, ~2000 at d = 16;
- *   backward (gdn_attn_aggregate_bwd): that tile at full d PLUS two [n, pitch] fp32 tables
- *     and the lists — n up to ~250 at d = 64 with k = 30 (127-sensor WADI, 51-sensor SWaT
- *     and the 25-55-sensor MSL/SMAP/PSM sets fit; the 512-sensor stress shape trains
- *     only at d <= 16);
+ *   backward (gdn_attn_aggregate_bwd): that tile at full d PLUS two [n, pitch] fp32 tables and the lists
+ *     in LDS — n up to ~250 at d = 64 with k = 30 (127-sensor WADI, 51-sensor SWaT, the 25-55-sensor
+ *     MSL/SMAP/PSM sets); beyond that gdn_attn_aggregate_bwd_ws keeps the tables in global memory and
+ *     only the tile must fit (n <= ~600 at d = 64: the 512-sensor / k = 64 stress shape trains);
+ *   matrix-core ("dense") kernels — gdn_forward_fused, gdn_project_fwd, gdn_attn_aggregate_fwd pick them
+ *     by themselves for n <= 127, d = 64, w <= 32, k <= 63; the bf16-storage entry points exist only there;
  * anything else returns GDN_ERR_UNSUPPORTED (never a silent fallback).
  */
 #ifndef GDN_HIP_H
@@ -43,7 +45,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 12
+#define GDN_ABI_VERSION 13
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -293,6 +295,19 @@ int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alp
                            const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
                            int batch, int n, int d, int k,
                            float* d_xlin, float* d_si, float* d_sj, float* d_bias, void* stream);
+
+/* Large sensor counts: when the tile plus the two [n, pitch] tables exceed LDS (n ~> 250 at d = 64,
+ * k = 30; the 512-sensor / k = 64 stress shape), the tables go through global memory and d_pi through a
+ * caller workspace of gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, k) bytes (0 = not needed, the
+ * plain entry point works).  The tile itself must fit: (n+1) * d * 4 bytes <= ~155 KB (n <= ~600 at
+ * d = 64).                                                                                           */
+long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, int d, int k);
+int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, const float* alpha,
+                              const float* s_i, const float* s_j,
+                              const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
+                              int batch, int n, int d, int k,
+                              float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                              float* workspace, void* stream);
 
 /* Reverse neighbour lists for the backward gather: rent[n, gdn_rev_pitch(n)] u32 holds, for
  * source j, (target << 16 | slot) of every list entry that names j, ascending target;

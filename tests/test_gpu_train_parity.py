@@ -559,3 +559,32 @@ def test_native_step_state_follows_checkpoint_round_trip(gpu_device):
     x = torch.rand((8, 27, 10), device=gpu_device)
     with torch.no_grad():
         assert torch.equal(model(x, None), fresh(x, None))
+
+
+def test_training_step_at_the_512_sensor_stress_shape(gpu_device):
+    """BASELINE configs[4] shape (512 sensors, top-k 64, W=30, d=64): the backward's two [n, pitch] tables
+    (164 KB each) cannot sit in LDS, gdn_attn_aggregate_bwd_ws runs them through global memory.  One training
+    step against the float64 oracle (loss and every gradient); the reference trains at any n."""
+    from oracle import gdn_oracle
+    from test_gpu_forward_parity import random_params
+    n, w, k, d, b = 512, 30, 64, 64, 2
+    model = random_params(n, w, k, d, seed=21)
+    p = {key: v.detach().clone() for key, v in model.state_dict().items()}
+    model = model.to(gpu_device).train()
+    g = torch.Generator().manual_seed(22)
+    x, y = torch.rand((b, n, w), generator=g), torch.rand((b, n), generator=g)
+    mask = (torch.rand((b, n, d), generator=g) >= 0.2).float() / 0.8
+    model.dp = FixedMaskDropout([mask.to(gpu_device)])
+    model.zero_grad()
+    loss = torch.nn.functional.mse_loss(model(x.to(gpu_device), None), y.to(gpu_device))
+    loss.backward()
+    graph = model.learned_graph.cpu()
+    f64 = torch.float64
+    leaf = {key: (v.to(f64).requires_grad_("running" not in key) if v.is_floating_point() else v) for key, v in p.items()}
+    r = gdn_oracle.forward(leaf, x.to(f64), k, training=True, dropout_mask=mask.to(f64), graph=graph)
+    ref_loss = torch.nn.functional.mse_loss(r["out"], y.to(f64))
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-6
+    for name, prm in model.named_parameters():
+        np.testing.assert_allclose(prm.grad.cpu().numpy().astype(np.float64), leaf[name].grad.numpy(), atol=2e-6,
+                                   rtol=1e-5, err_msg=name)
