@@ -504,14 +504,28 @@ class AutogradTrainStep:
         # two graphs around the (eager) gradient all-reduce; forced on by `split=True` for rehearsal
         self._split = world()[1] > 1 if split is None else bool(split)
         self._flat = None                                # static gradient bucket (split mode)
+        import os
+        self._torch_mse = bool(os.environ.get("GDN_TORCH_MSE"))
+        self._dbg = None                                 # diagnostic snapshot buffers (tools/probe_mse_replay.py)
 
     # the two halves of a step; `loss` is written in place so it survives replays
     def _forward_backward(self):
         self.optimizer.zero_grad(set_to_none=True)      # backward then writes fresh gradients: no fill, no add
         out = self.model(self.x, None)
-        # loss + its gradient in one launch (train.py:20-23, :72); autograd starts from d_out
-        ops.mse_loss_grad(out.detach(), self.y, self._mse_ws, loss=self.loss, d_out=self._d_out)
-        out.backward(self._d_out)
+        if self._torch_mse:     # diagnostic (tools/probe_mse_replay.py): the round-1 form with torch's reduction
+            loss = F.mse_loss(out, self.y, reduction="mean")
+            loss.backward()
+            self.loss.copy_(loss.detach())
+            if self._dbg is not None:
+                self._dbg["out"].copy_(out.detach())
+                self._dbg["loss_raw"].copy_(loss.detach())
+        else:
+            # loss + its gradient in one launch (train.py:20-23, :72); autograd starts from d_out
+            ops.mse_loss_grad(out.detach(), self.y, self._mse_ws, loss=self.loss, d_out=self._d_out)
+            out.backward(self._d_out)
+        if self._dbg is not None:
+            for name, prm in self.model.named_parameters():
+                self._dbg["g/" + name].copy_(prm.grad)
         if self._split:                                  # the bucket is part of the first graph
             if self._flat is None:
                 self._flat = pack_gradients(self.model)
