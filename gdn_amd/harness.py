@@ -173,13 +173,17 @@ class HipScoreBackend:
         return ops.score_keys(pred_tn, gt_tn, pitch, out=out)
 
     @staticmethod
-    def select(keys_flat, blocks, n, pitch, total):
-        return ops.score_select(keys_flat, blocks, n, pitch, total)
+    def select(keys_flat, blocks, n, pitch, total, ws=None, out=None):
+        return ops.score_select(keys_flat, blocks, n, pitch, total, ws=ws, out=out)
 
     @staticmethod
-    def smooth_max(pred_tn, gt_tn, med_iqr, first_tick, halo_pred, halo_gt):
+    def select_workspace(blocks, n, pitch, device):
+        return ops.score_select_workspace(blocks, n, pitch, device)
+
+    @staticmethod
+    def smooth_max(pred_tn, gt_tn, med_iqr, first_tick, halo_pred, halo_gt, anomaly=None):
         return ops.score_smooth_max(pred_tn, gt_tn, med_iqr, want_scores=False, first_tick=first_tick,
-                                    halo_pred=halo_pred, halo_gt=halo_gt)[1]
+                                    halo_pred=halo_pred, halo_gt=halo_gt, anomaly=anomaly)[1]
 
 
 def distributed_anomaly(pred_local, gt_local, total_ticks: int, backend=HipScoreBackend, group=None,
@@ -316,6 +320,16 @@ class ShardedEvaluator:
                     for which in (0, 1)]
         self.halo_idx = torch.tensor(halo_idx, dtype=torch.int64, device=dev)
         self.forward = forward if forward is not None else self._hip_forward
+        # per-step buffers of the scoring kernels, allocated once (backends without the hooks allocate per call)
+        self._sel_ws = self._sel_out = self._anomaly = None
+        if hasattr(backend, "select_workspace") and self.n_mine:
+            self._sel_ws = backend.select_workspace(self.nchunks * size, self.n_mine, self.pitch, dev)
+            self._sel_out = torch.empty((self.n_mine, 2), dtype=torch.float64, device=dev)
+        if hasattr(backend, "select_workspace") and self.t:
+            self._anomaly = torch.empty((self.t,), dtype=torch.float64, device=dev)
+        self._med_iqr = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        self._halo64 = torch.empty((2, 3, n), dtype=torch.float64, device=dev)
+        self._halo = torch.empty((2, 3, n), dtype=torch.float32, device=dev)
 
     def _hip_forward(self, start, stop):
         self.model.forward_into(self.x[start:stop], self.pred[start:stop])
@@ -332,20 +346,24 @@ class ShardedEvaluator:
         for w in works:
             w.wait()
         if self.n_mine:
+            extra = {"ws": self._sel_ws, "out": self._sel_out} if self._sel_ws is not None else {}
             mi = self.backend.select(self.recv.reshape(-1), self.nchunks * self.size, self.n_mine, self.pitch,
-                                     self.total)
+                                     self.total, **extra)
             self.pub[: self.n_mine * 2] = mi.reshape(-1)
         if self.take:
             self.pub[self.cap * 2:].view(2, 3, self.n)[0, 3 - self.take:] = self.pred[self.t - self.take:]
         dist.all_gather_into_tensor(self.gathered, self.pub, group=self.group)
-        med_iqr = self.gathered[self.mi_idx].view(self.n, 2)
+        torch.index_select(self.gathered, 0, self.mi_idx, out=self._med_iqr.view(-1))
+        med_iqr = self._med_iqr
         halo_p = halo_g = None
         if self.first_tick > 0:
-            halo = self.gathered[self.halo_idx].to(self.pred.dtype)
-            halo_p, halo_g = halo[0], halo[1]
+            torch.index_select(self.gathered, 0, self.halo_idx.view(-1), out=self._halo64.view(-1))
+            self._halo.copy_(self._halo64)
+            halo_p, halo_g = self._halo[0], self._halo[1]
         if self.t == 0:
             return torch.empty((0,), dtype=torch.float64, device=self.pred.device)
-        return self.backend.smooth_max(self.pred, self.y, med_iqr, self.first_tick, halo_p, halo_g)
+        extra = {"anomaly": self._anomaly} if self._anomaly is not None else {}
+        return self.backend.smooth_max(self.pred, self.y, med_iqr, self.first_tick, halo_p, halo_g, **extra)
 
 
 # --------------------------------------------------------------------------- resident-series evaluator
@@ -601,6 +619,24 @@ class AutogradTrainStep:
         return self.loss
 
 
+def flat_layout(params):
+    """Slots of the flat parameter / gradient / optimizer-state buffers: [(offset, count)] per parameter, every
+    slot on a 16-byte boundary (the kernels read rows as float4), and the padded total."""
+    slices, total = [], 0
+    for p in params:
+        slices.append((total, p.numel()))
+        total += (p.numel() + 3) & ~3
+    return slices, total
+
+
+def all_reduce_flat(flat_g, group=None):
+    """The one collective of a data-parallel training step: the flat gradient buffer is summed over the ranks
+    as it stands (the 1/ranks is applied by gdn_adam_step's grad_scale).  No-op in a single process."""
+    if world()[1] > 1:
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / max(1, world()[1])
+
+
 class _FlatAdam:
     """What `train()` needs from an optimizer for the batches that do not go through the captured step (the
     ragged last batch of an epoch): zero_grad() / step() over the SAME flat Adam state as the native step."""
@@ -661,10 +697,7 @@ class NativeTrainStep:
         self.lr, self.wd = float(lr), float(weight_decay)
         self.params = list(model.parameters())
         # flat parameter buffer; every slot starts on a 16-byte boundary (the kernels read rows as float4)
-        self.slices, total = [], 0
-        for p in self.params:
-            self.slices.append((total, p.numel()))
-            total += (p.numel() + 3) & ~3
+        self.slices, total = flat_layout(self.params)
         self.count = total
         self.flat_p = torch.zeros((total,), dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -771,8 +804,7 @@ class NativeTrainStep:
              G(g + "att_em_i"), G(g + "att_em_j"), G("embedding.weight"), 1, st)
 
     def _all_reduce(self):
-        if world()[1] > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+        all_reduce_flat(self.flat_g)
 
     def _adam(self):
         self._lib.call("gdn_adam_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),

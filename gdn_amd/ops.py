@@ -382,12 +382,20 @@ def score_keys(pred, gt, pitch: int, out: torch.Tensor | None = None) -> torch.T
     return keys
 
 
-def score_select(keys, blocks: int, n: int, pitch: int, total: int) -> torch.Tensor:
-    """Median / IQR per sensor over keys[blocks, n, pitch] holding `total` real keys per sensor."""
-    keys = _chk(keys, torch.float64, "keys")
+def score_select_workspace(blocks: int, n: int, pitch: int, device) -> torch.Tensor:
     nbytes = _lib.load().gdn_score_select_workspace_bytes(blocks, n, pitch)
-    ws = torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=keys.device)
-    out = torch.empty((n, 2), dtype=torch.float64, device=keys.device)
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=device)
+
+
+def score_select(keys, blocks: int, n: int, pitch: int, total: int, ws: torch.Tensor | None = None,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """Median / IQR per sensor over keys[blocks, n, pitch] holding `total` real keys per sensor.
+    `ws` (score_select_workspace) and `out` [n, 2] float64 may be preallocated (no allocation per call)."""
+    keys = _chk(keys, torch.float64, "keys")
+    if ws is None:
+        ws = score_select_workspace(blocks, n, pitch, keys.device)
+    if out is None:
+        out = torch.empty((n, 2), dtype=torch.float64, device=keys.device)
     _lib.call("gdn_score_select", _ptr(keys), blocks, n, pitch, total, _ptr(ws), _ptr(out), _stream())
     return out
 
@@ -404,12 +412,14 @@ def score_quantiles(pred, gt):
 
 
 def score_smooth_max(pred, gt, med_iqr, want_scores: bool = True, first_tick: int = 0,
-                     halo_pred=None, halo_gt=None):
-    """evaluate.py:54-68 + the max over sensors of :131-139.  Returns (scores[n,t] | None, anomaly[t])."""
+                     halo_pred=None, halo_gt=None, anomaly: torch.Tensor | None = None):
+    """evaluate.py:54-68 + the max over sensors of :131-139.  Returns (scores[n,t] | None, anomaly[t]);
+    `anomaly` may be a preallocated float64 [t] buffer."""
     pred, gt = _chk(pred, name="pred"), _chk(gt, name="gt")
     t, n = pred.shape
     scores = torch.empty((n, t), dtype=torch.float64, device=pred.device) if want_scores else None
-    anomaly = torch.empty((t,), dtype=torch.float64, device=pred.device)
+    if anomaly is None:
+        anomaly = torch.empty((t,), dtype=torch.float64, device=pred.device)
     hp = None if halo_pred is None else _chk(halo_pred, name="halo_pred")
     hg = None if halo_gt is None else _chk(halo_gt, name="halo_gt")
     _lib.call("gdn_score_smooth_max", _ptr(pred), _ptr(gt), _ptr(_chk(med_iqr, torch.float64)), t, n,

@@ -103,6 +103,59 @@ def main():
     harness.sync_gradients(model)
     for p, buf in zip(model.parameters(), gathered):
         torch.testing.assert_close(p.grad, sum(buf) / size)
+    # ---- the data-parallel TRAINING step of harness.NativeTrainStep, host logic on CPU: every rank runs the
+    # model (here: the oracle, float64) on ITS shard of the global batch with ITS OWN BatchNorm statistics
+    # (standard DDP), writes the gradients into the flat bucket (harness.flat_layout), the bucket
+    # is all-reduced as it stands (harness.all_reduce_flat) and Adam runs with grad_scale = 1/ranks.
+    # Reference: the same per-shard gradients averaged in one process + torch.optim.Adam.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden, meta
+    from oracle import gdn_oracle
+    data, p = load_golden("msl_demo_w5_k5")
+    m = meta(data)
+    names = [k for k in p if "running" not in k and "num_batches" not in k]
+    f64 = torch.float64
+
+    def shard_grads(r):
+        """Gradients of rank r's shard (batch rows r::size), BatchNorm statistics of that shard only."""
+        leaf = {k: (v.to(f64).clone().requires_grad_(k in names) if v.is_floating_point() else v) for k, v in p.items()}
+        xb = torch.from_numpy(data["x"])[r::size].to(f64)
+        yb = torch.from_numpy(data["y"])[r::size].to(f64)
+        out = gdn_oracle.forward(leaf, xb, m["k"], training=True,
+                                 dropout_mask=torch.from_numpy(data["dropout_mask"])[r::size].to(f64),
+                                 graph=torch.from_numpy(data["learned_graph"]))["out"]
+        torch.nn.functional.mse_loss(out, yb).backward()
+        return [leaf[k].grad for k in names]
+
+    params = [p[k].to(f64).clone() for k in names]
+    slices, count = harness.flat_layout(params)
+    assert all(off % 4 == 0 for off, _ in slices) and count % 4 == 0
+    flat_p = torch.zeros((count,), dtype=f64)
+    flat_g = torch.zeros((count,), dtype=f64)
+    for prm, (off, cnt) in zip(params, slices):
+        flat_p[off:off + cnt] = prm.reshape(-1)
+    for gr, (off, cnt) in zip(shard_grads(rank), slices):
+        flat_g[off:off + cnt] = gr.reshape(-1)
+    scale = harness.all_reduce_flat(flat_g)
+    assert scale == 1.0 / size
+    # gdn_adam_step's update (include/gdn_hip.h), first step: m = (1-b1) g, v = (1-b2) g^2
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    gs = flat_g * scale
+    m1, v1 = (1 - b1) * gs, (1 - b2) * gs * gs
+    flat_p = flat_p - (lr / (1 - b1)) * m1 / (v1.sqrt() / (1 - b2) ** 0.5 + eps)
+    # reference
+    ref_params = [torch.nn.Parameter(p[k].to(f64).clone()) for k in names]
+    per_rank = [shard_grads(r) for r in range(size)]
+    opt = torch.optim.Adam(ref_params, lr=lr)
+    for i, prm in enumerate(ref_params):
+        prm.grad = sum(per_rank[r][i] for r in range(size)) / size
+    opt.step()
+    for prm, (off, cnt), name in zip(ref_params, slices, names):
+        torch.testing.assert_close(flat_p[off:off + cnt].view(prm.shape), prm.detach(), rtol=1e-9, atol=1e-12, msg=name)
+    # per-rank BatchNorm statistics really differ from the global-batch ones (the step is DDP, not SyncBN)
+    if size > 1:
+        assert not torch.allclose(per_rank[0][names.index("gnn_layers.0.gnn.lin.weight")],
+                                  per_rank[1][names.index("gnn_layers.0.gnn.lin.weight")])
     # identical parameters on every rank after the broadcast
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     ref = flat.clone()
