@@ -1,0 +1,248 @@
+"""Command line of the reference (main.py:199-256, run.sh:4-58), same flags and printed report:
+
+    python -m gdn_amd.main -dataset msl -device cuda -slide_win 15 -topk 20 -batch 128 -epoch 30 ...
+    bash run.sh 0 msl            (the reference's `bash run.sh <gpu_n> <dataset>`)
+
+Reads ./data/<dataset>/{train.csv,test.csv,list.txt} exactly like main.py:44-53 (`-data_root` moves the
+directory), builds the model with the reference's seeds and constructor (same initial weights), trains
+with the reference's loop (harness.train: Adam 1e-3, best-validation checkpoint, early stop), evaluates
+and prints `F1 score / precision / recall`.
+
+What is different is WHERE the data lives: the two series stay in HBM as [N, T]
+tensors and every window is cut from them on the device —
+  * training batches: the DataLoader of main.py:128-148 is kept for what it decides (the random
+    contiguous validation block, the shuffled order: same RNG draws as the reference), but it yields
+    window INDICES; the [batch, N, W] block is gathered from the resident series (stride
+    `slide_stride`, datasets/TimeDataset.py:44-58) by one device op;
+  * evaluation: `GDN.forward_series` builds the stride-1 windows inside the kernel; predictions, the
+    anomaly scores and the threshold sweep never leave the device (gdn_amd/evaluate.py).
+The reference's `TimeDataset` would materialise a W-fold copy of both series on the host."""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Subset, TensorDataset
+
+from . import evaluate, harness
+from .model import GDN
+
+
+def get_feature_map(dataset, data_root="./data"):
+    """util/net_struct.py:4-10."""
+    with open(os.path.join(data_root, dataset, "list.txt")) as f:
+        return [ft.strip() for ft in f]
+
+
+def get_fc_graph_struc(dataset, data_root="./data"):
+    """util/net_struct.py:12-28: every feature's children = all the others."""
+    feats = get_feature_map(dataset, data_root)
+    return {ft: [o for o in feats if o is not ft] for ft in feats}
+
+
+def build_loc_net(struc, all_features, feature_map):
+    """util/preprocess.py:85-116: [2, E] (child index, parent index) of the prior graph.  The model ignores it
+    (models/GDN.py:122) — built for API parity (`GDN(edge_index_sets, ...)`)."""
+    src, dst = [], []
+    for node, children in struc.items():
+        if node not in all_features:
+            continue
+        if node not in feature_map:
+            feature_map.append(node)
+        p = feature_map.index(node)
+        for child in children:
+            if child in all_features and child in feature_map:
+                src.append(feature_map.index(child))
+                dst.append(p)
+    return [src, dst]
+
+
+def read_series(path, feature_map, want_labels):
+    """main.py:44-64 + util/preprocess.py:67-83: columns in feature-map order -> [N, T] float64, labels [T]."""
+    import pandas as pd
+    df = pd.read_csv(path, sep=",", index_col=0)
+    labels = df["attack"].to_numpy(dtype=np.float64) if want_labels and "attack" in df.columns else np.zeros(len(df))
+    cols = [ft for ft in feature_map if ft in df.columns]
+    return np.ascontiguousarray(df[cols].to_numpy(dtype=np.float64).T), labels
+
+
+class SeriesWindows:
+    """datasets/TimeDataset.py for a series resident on the device: window i covers columns
+    [starts[i] - W, starts[i]) and predicts column starts[i]; `batch(idx)` gathers x[B,N,W], y[B,N], labels[B]."""
+
+    def __init__(self, series_nt: torch.Tensor, labels_t: torch.Tensor, slide_win: int, slide_stride: int, mode: str):
+        self.series, self.labels, self.w = series_nt, labels_t, slide_win
+        t_len = series_nt.shape[1]
+        rng = range(slide_win, t_len, slide_stride) if mode == "train" else range(slide_win, t_len)
+        self.starts = torch.tensor(list(rng), dtype=torch.int64, device=series_nt.device)
+        self._offs = torch.arange(-slide_win, 0, device=series_nt.device)
+
+    def __len__(self):
+        return int(self.starts.numel())
+
+    def batch(self, idx: torch.Tensor):
+        at = self.starts[idx.to(self.starts.device)]
+        cols = at.view(-1, 1) + self._offs.view(1, -1)                       # [B, W]
+        x = self.series[:, cols].permute(1, 0, 2).contiguous()               # [B, N, W]
+        return x, self.series[:, at].t().contiguous(), self.labels[at]
+
+
+class IndexLoader:
+    """A torch DataLoader over window indices (so that shuffling draws what the reference's loader draws),
+    yielding (x, y, labels, edge_index) device batches like the reference's loaders."""
+
+    def __init__(self, windows: SeriesWindows, indices: torch.Tensor, batch: int, shuffle: bool, edge_index):
+        self.windows, self.edge_index = windows, edge_index
+        self.loader = DataLoader(TensorDataset(indices), batch_size=batch, shuffle=shuffle, num_workers=0)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for (idx,) in self.loader:
+            x, y, lab = self.windows.batch(idx)
+            yield x, y, lab, self.edge_index
+
+
+class Main:
+    """main.py:36-195."""
+
+    def __init__(self, train_config, env_config, debug=False):
+        self.train_config, self.env_config, self.datestr = train_config, env_config, None
+        dataset, root = env_config["dataset"], env_config.get("data_root", "./data")
+        if env_config["device"] == "cpu":
+            raise SystemExit("gdn_amd has no CPU path (the reference's `-device cpu` runs the reference)")
+        self.device = torch.device("cuda", 0)                               # util/env.py: `cuda` + CUDA_VISIBLE_DEVICES
+        feature_map = get_feature_map(dataset, root)
+        fc_struc = get_fc_graph_struc(dataset, root)
+        train_np, _ = read_series(os.path.join(root, dataset, "train.csv"), feature_map, want_labels=False)
+        test_np, test_labels = read_series(os.path.join(root, dataset, "test.csv"), feature_map, want_labels=True)
+        self.feature_map = feature_map
+        fc_edge_index = torch.tensor(build_loc_net(fc_struc, list(feature_map), feature_map=feature_map), dtype=torch.long)
+        dev = self.device
+        # TimeDataset holds float64 and the loops cast to float32 (train.py:66, test.py:44)
+        self.train_series = torch.from_numpy(train_np).to(dev).float()
+        self.test_series = torch.from_numpy(test_np).to(dev).float()
+        self.test_labels = torch.from_numpy(test_labels).to(dev)
+        cfg = dict(slide_win=train_config["slide_win"], slide_stride=train_config["slide_stride"])
+        self.train_dataset = SeriesWindows(self.train_series, torch.zeros(train_np.shape[1], device=dev, dtype=torch.float64),
+                                           cfg["slide_win"], cfg["slide_stride"], "train")
+        self.test_dataset = SeriesWindows(self.test_series, self.test_labels, cfg["slide_win"], cfg["slide_stride"], "test")
+        self.train_dataloader, self.val_dataloader = self.get_loaders(
+            self.train_dataset, train_config["seed"], train_config["batch"], val_ratio=train_config["val_ratio"],
+            edge_index=fc_edge_index)
+        self.model = GDN([fc_edge_index], len(feature_map), dim=train_config["dim"], input_dim=train_config["slide_win"],
+                         out_layer_num=train_config["out_layer_num"],
+                         out_layer_inter_dim=train_config["out_layer_inter_dim"], topk=train_config["topk"]).to(dev)
+
+    def get_loaders(self, train_dataset, seed, batch, val_ratio=0.1, edge_index=None):
+        """main.py:128-148: a random contiguous validation block, shuffled training order."""
+        dataset_len = int(len(train_dataset))
+        train_use_len = int(dataset_len * (1 - val_ratio))
+        val_use_len = int(dataset_len * val_ratio)
+        val_start_index = random.randrange(train_use_len)
+        indices = torch.arange(dataset_len)
+        train_idx = torch.cat([indices[:val_start_index], indices[val_start_index + val_use_len:]])
+        val_idx = indices[val_start_index:val_start_index + val_use_len]
+        return (IndexLoader(train_dataset, train_idx, batch, True, edge_index),
+                IndexLoader(train_dataset, val_idx, batch, False, edge_index))
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self):
+        if len(self.env_config["load_model_path"]) > 0:
+            model_save_path = self.env_config["load_model_path"]
+        else:
+            model_save_path = self.get_save_path()[0]
+            self.train_log = harness.train(self.model, model_save_path, config=self.train_config,
+                                           train_dataloader=self.train_dataloader, val_dataloader=self.val_dataloader,
+                                           use_graph=bool(self.train_config.get("hip_graph", True)))
+        self.model.load_state_dict(torch.load(model_save_path, weights_only=True))
+        best_model = self.model.to(self.device).eval()
+        # test.py's loop with the windows built in the kernel from the resident series (stride 1)
+        w = self.train_config["slide_win"]
+        n_test = self.test_series.shape[1] - w
+        pred = best_model.forward_series(self.test_series, 0, n_test) if best_model.out_layer_num == 1 else \
+            torch.cat([best_model(x, None) for x, _y, _l, _e in IndexLoader(
+                self.test_dataset, torch.arange(n_test), self.train_config["batch"], False, None)])
+        gt = self.test_series[:, w:].t().contiguous()
+        labels = self.test_labels[w:]
+        self.test_result = [pred, gt, labels.view(-1, 1).expand(-1, pred.shape[1])]
+        _, self.val_result = harness.test(best_model, self.val_dataloader, self.device, as_tensors=True)
+        return self.get_score(self.test_result, self.val_result)
+
+    def get_score(self, test_result, val_result):
+        """main.py:150-174."""
+        test_labels = test_result[2][:, 0]
+        test_scores, _, _ = evaluate.anomaly_scores(test_result[0], test_result[1], device=self.device)
+        if self.env_config["report"] == "best":
+            info = evaluate.get_best_performance_data(test_scores, test_labels, topk=1, device=self.device)
+        else:
+            normal_scores, _, _ = evaluate.anomaly_scores(val_result[0], val_result[1], device=self.device)
+            info = evaluate.get_val_performance_data(test_scores, normal_scores, test_labels, topk=1, device=self.device)
+        print("=========================** Result **============================\n")
+        print(f"F1 score: {info[0]}")
+        print(f"precision: {info[1]}")
+        print(f"recall: {info[2]}\n")
+        return info
+
+    def get_save_path(self, feature_name=""):
+        """main.py:177-195."""
+        dir_path = self.env_config["save_path"]
+        if self.datestr is None:
+            self.datestr = datetime.now().strftime("%m|%d-%H:%M:%S")
+        paths = [f"./pretrained/{dir_path}/best_{self.datestr}.pt", f"./results/{dir_path}/{self.datestr}.csv"]
+        for path in paths:
+            Path(os.path.dirname(path)).mkdir(parents=True, exist_ok=True)
+        return paths
+
+
+def build_parser():
+    """main.py:199-217 (single-dash long flags and defaults as in the reference) + -data_root / -no_hip_graph."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-batch", help="batch size", type=int, default=128)
+    parser.add_argument("-epoch", help="train epoch", type=int, default=100)
+    parser.add_argument("-slide_win", help="slide_win", type=int, default=15)
+    parser.add_argument("-dim", help="dimension", type=int, default=64)
+    parser.add_argument("-slide_stride", help="slide_stride", type=int, default=5)
+    parser.add_argument("-save_path_pattern", help="save path pattern", type=str, default="")
+    parser.add_argument("-dataset", help="wadi / swat", type=str, default="wadi")
+    parser.add_argument("-device", help="cuda / cpu", type=str, default="cuda")
+    parser.add_argument("-random_seed", help="random seed", type=int, default=0)
+    parser.add_argument("-comment", help="experiment comment", type=str, default="")
+    parser.add_argument("-out_layer_num", help="outlayer num", type=int, default=1)
+    parser.add_argument("-out_layer_inter_dim", help="out_layer_inter_dim", type=int, default=256)
+    parser.add_argument("-decay", help="decay", type=float, default=0)
+    parser.add_argument("-val_ratio", help="val ratio", type=float, default=0.1)
+    parser.add_argument("-topk", help="topk num", type=int, default=20)
+    parser.add_argument("-report", help="best / val", type=str, default="best")
+    parser.add_argument("-load_model_path", help="trained model path", type=str, default="")
+    parser.add_argument("-data_root", help="directory holding <dataset>/train.csv, test.csv, list.txt", type=str, default="./data")
+    parser.add_argument("-no_hip_graph", help="launch every training step eagerly", action="store_true")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    random.seed(args.random_seed)                      # main.py:221-228
+    np.random.seed(args.random_seed)
+    torch.manual_seed(args.random_seed)
+    torch.cuda.manual_seed(args.random_seed)
+    torch.cuda.manual_seed_all(args.random_seed)
+    os.environ["PYTHONHASHSEED"] = str(args.random_seed)
+    train_config = {"batch": args.batch, "epoch": args.epoch, "slide_win": args.slide_win, "dim": args.dim,
+                    "slide_stride": args.slide_stride, "comment": args.comment, "seed": args.random_seed,
+                    "out_layer_num": args.out_layer_num, "out_layer_inter_dim": args.out_layer_inter_dim,
+                    "decay": args.decay, "val_ratio": args.val_ratio, "topk": args.topk,
+                    "hip_graph": not args.no_hip_graph}
+    env_config = {"save_path": args.save_path_pattern, "dataset": args.dataset, "report": args.report,
+                  "device": args.device, "load_model_path": args.load_model_path, "data_root": args.data_root}
+    return Main(train_config, env_config, debug=False).run()
+
+
+if __name__ == "__main__":
+    main()

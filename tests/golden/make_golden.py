@@ -369,6 +369,87 @@ def performance_cases():
         print(f"{name}: best {out['best_top1']} val {out['val_top1']}")
 
 
+def cli_case():
+    """SURVEY §8f-4, second half: the reference's command line end to end — main.py:36-195 (`Main`, data
+    loading, loaders, model construction, test(), get_score) driven with -load_model_path on a slice of the
+    reference's own demo data (data/msl: first 400 training rows, first 700 test rows, which contain an
+    attack segment).  Stored: the data slice, the checkpoint, and the (F1, precision, recall, AUC, threshold)
+    tuples behind the printed report for -report best and -report val."""
+    import contextlib
+    import io
+    import random
+    import shutil
+    import types
+    import pandas as pd
+    scratch = "/tmp/gdn_golden_cli"
+    shutil.rmtree(scratch, ignore_errors=True)
+    os.makedirs(os.path.join(scratch, "data", "msl"))
+    tr = pd.read_csv(os.path.join(REF, "data/msl/train.csv"), sep=",", index_col=0).iloc[:400]
+    te = pd.read_csv(os.path.join(REF, "data/msl/test.csv"), sep=",", index_col=0).iloc[:700]
+    assert 0 < te["attack"].sum() < len(te)
+    tr.to_csv(os.path.join(scratch, "data/msl/train.csv"))
+    te.to_csv(os.path.join(scratch, "data/msl/test.csv"))
+    shutil.copy(os.path.join(REF, "data/msl/list.txt"), os.path.join(scratch, "data/msl/list.txt"))
+    # `datasets` on this image is HuggingFace's package: bind the name to the reference's directory
+    pkg = types.ModuleType("datasets")
+    pkg.__path__ = [os.path.join(REF, "datasets")]
+    saved_ds = sys.modules.get("datasets")
+    sys.modules["datasets"] = pkg
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        ref_main = _load_by_path("ref_main", os.path.join(REF, "main.py"))
+        seed = 5
+        cfg = dict(batch=32, epoch=1, slide_win=5, dim=64, slide_stride=1, comment="", seed=seed, out_layer_num=1,
+                   out_layer_inter_dim=128, decay=0, val_ratio=0.2, topk=5)
+        out = {}
+        for report in ("best", "val"):
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)      # main.py:221-224
+            env = dict(save_path="msl", dataset="msl", report=report, device="cpu", load_model_path="")
+            m = ref_main.Main(cfg, env, debug=False)
+            if report == "best":
+                g = torch.Generator().manual_seed(77)
+                with torch.no_grad():                       # a checkpoint with non-trivial BatchNorm statistics
+                    for bn in (m.model.gnn_layers[0].bn, m.model.bn_outlayer_in):
+                        bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=g) * 0.1)
+                        bn.running_var.copy_(torch.rand(bn.running_var.shape, generator=g) + 0.5)
+                ckpt = os.path.join(scratch, "ckpt.pt")
+                torch.save(m.model.state_dict(), ckpt)
+                out.update(state_arrays(m.model.state_dict(), "p/"))
+            m.env_config["load_model_path"] = ckpt
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                m.run()
+            printed = [ln for ln in buf.getvalue().splitlines() if ":" in ln]
+            vals = [float(ln.split(":")[1]) for ln in printed if ln.split(":")[0] in ("F1 score", "precision", "recall")]
+            test_labels = np.array(m.test_result)[2, :, 0].tolist()
+            scores, normal = ref_eval.get_full_err_scores(m.test_result, m.val_result)
+            info = (ref_eval.get_best_performance_data(scores, test_labels, topk=1) if report == "best"
+                    else ref_eval.get_val_performance_data(scores, normal, test_labels, topk=1))
+            assert np.allclose(vals, info[:3])
+            out["info_" + report] = np.array(info, dtype=np.float64)
+            if report == "best":
+                out["test_pred"] = np.array(m.test_result[0], dtype=np.float32)
+                out["test_scores_top1"] = np.max(scores, axis=0)
+                out["val_indices"] = np.array(m.val_dataloader.dataset.indices)
+        out["train_raw"] = tr.to_numpy(dtype=np.float64)
+        out["test_raw"] = te.to_numpy(dtype=np.float64)          # last column = attack
+        out["columns_train"] = np.array(list(tr.columns))
+        out["columns_test"] = np.array(list(te.columns))
+        out["features"] = np.array([ln.strip() for ln in open(os.path.join(scratch, "data/msl/list.txt"))])
+        out["meta_cfg"] = np.array([cfg["batch"], cfg["slide_win"], cfg["dim"], cfg["slide_stride"], cfg["topk"], seed,
+                                    cfg["out_layer_inter_dim"]], dtype=np.int64)
+        out["val_ratio"] = np.array(cfg["val_ratio"])
+        np.savez_compressed(os.path.join(HERE, "cli_msl_slice.npz"), **out)
+        print("cli_msl_slice: best", out["info_best"], "val", out["info_val"])
+    finally:
+        os.chdir(cwd)
+        if saved_ds is not None:
+            sys.modules["datasets"] = saved_ds
+        else:
+            sys.modules.pop("datasets", None)
+
+
 def full_batch_cases():
     """BASELINE.json configs as worded, at their stated batch (round 2)."""
     xs, _ys, raw = msl_slice(15, 128)
@@ -382,6 +463,9 @@ def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "full-batch":
         full_batch_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cli":
+        cli_case()
         return
     xs, ys, raw = msl_slice(5, 8)
     run_case("msl_demo_w5_k5", seed=5, b=8, n=27, w=5, k=5, x=xs, y=ys,
@@ -401,6 +485,7 @@ def main():
     score_cases()
     performance_cases()
     full_batch_cases()
+    cli_case()
 
 
 if __name__ == "__main__":

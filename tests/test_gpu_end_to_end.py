@@ -1,9 +1,13 @@
 """GPU suite: the whole path used the way the reference uses it (main.py:103-147): train on a normal
 series, predict a test series, score it, and find the injected fault.  A functional check — the
 numbers are not the reference's (synthetic data, no fixture); parity is pinned elsewhere."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -67,3 +71,70 @@ def test_train_eval_score_finds_injected_fault(gpu_device):
     # the resident-series evaluator gives the same anomaly score as the loop above
     ev = harness.SeriesEvaluator(model, xte.to(gpu_device), yte.to(gpu_device), batch=256, use_graph=True)
     np.testing.assert_allclose(ev.step().cpu().numpy(), anomaly, rtol=1e-9, atol=1e-9)
+
+
+def _write_cli_dataset(data, root):
+    import pandas as pd
+    os.makedirs(os.path.join(root, "msl"), exist_ok=True)
+    pd.DataFrame(data["train_raw"], columns=[str(c) for c in data["columns_train"]]).to_csv(os.path.join(root, "msl", "train.csv"))
+    pd.DataFrame(data["test_raw"], columns=[str(c) for c in data["columns_test"]]).to_csv(os.path.join(root, "msl", "test.csv"))
+    with open(os.path.join(root, "msl", "list.txt"), "w") as f:
+        f.write("\n".join(str(c) for c in data["features"]) + "\n")
+
+
+@pytest.mark.parametrize("report", ["best", "val"])
+def test_command_line_reproduces_the_reference_report(report, gpu_device, tmp_path, capsys):
+    """`python -m gdn_amd.main` with the reference's flags on a slice of the reference's demo data
+    and a checkpoint written by the reference's model: same validation block (same RNG draws), same predictions,
+    same printed F1 / precision / recall as the reference's main.py (fixture: tests/golden/make_golden.py cli_case)."""
+    from gdn_amd import main as cli
+    data, p = load_golden("cli_msl_slice")
+    batch, w, dim, stride, topk, seed, inter = (int(v) for v in data["meta_cfg"])
+    root = str(tmp_path / "data")
+    _write_cli_dataset(data, root)
+    ckpt = str(tmp_path / "ckpt.pt")
+    torch.save(p, ckpt)
+    argv = ["-dataset", "msl", "-data_root", root, "-device", "cuda", "-batch", str(batch), "-slide_win", str(w),
+            "-dim", str(dim), "-slide_stride", str(stride), "-topk", str(topk), "-random_seed", str(seed),
+            "-out_layer_inter_dim", str(inter), "-val_ratio", str(float(data["val_ratio"])), "-report", report,
+            "-load_model_path", ckpt]
+    args = cli.build_parser().parse_args(argv)
+    import random
+    random.seed(args.random_seed)
+    torch.manual_seed(args.random_seed)
+    m = cli.Main({"batch": batch, "epoch": 1, "slide_win": w, "dim": dim, "slide_stride": stride, "comment": "",
+                  "seed": seed, "out_layer_num": 1, "out_layer_inter_dim": inter, "decay": 0,
+                  "val_ratio": float(data["val_ratio"]), "topk": topk},
+                 {"save_path": "msl", "dataset": "msl", "report": report, "device": "cuda", "load_model_path": ckpt,
+                  "data_root": root})
+    val_idx = m.val_dataloader.loader.dataset.tensors[0]
+    np.testing.assert_array_equal(val_idx.numpy(), data["val_indices"])          # the reference's random block
+    info = m.run()
+    printed = capsys.readouterr().out
+    assert "F1 score:" in printed and "precision:" in printed and "recall:" in printed
+    np.testing.assert_allclose(m.test_result[0].cpu().numpy(), data["test_pred"], atol=2e-5, rtol=0)
+    want = data["info_" + report]
+    # rank-based thresholds: a 1e-7 difference in two near-equal scores can move one tick across the threshold
+    np.testing.assert_allclose(info[:3], want[:3], atol=5e-3, rtol=0)
+    np.testing.assert_allclose(info[3], want[3], atol=2e-3, rtol=0)              # AUC
+    np.testing.assert_allclose(info[4], want[4], rtol=1e-4)                      # threshold
+    # and the whole command line through main(): prints the same three lines
+    cli.main(argv)
+    out2 = capsys.readouterr().out
+    f1 = float([ln for ln in out2.splitlines() if ln.startswith("F1 score:")][0].split(":")[1])
+    assert abs(f1 - info[0]) < 1e-12
+
+
+def test_command_line_trains_and_reports(gpu_device, tmp_path, capsys, monkeypatch):
+    """The training branch of the command line (no -load_model_path): 2 epochs on the demo slice with the native
+    HIP-graph step, best-validation checkpoint written under ./pretrained/<pattern>/, report printed."""
+    from gdn_amd import main as cli
+    data, _p = load_golden("cli_msl_slice")
+    root = str(tmp_path / "data")
+    _write_cli_dataset(data, root)
+    monkeypatch.chdir(tmp_path)
+    info = cli.main(["-dataset", "msl", "-data_root", root, "-batch", "32", "-slide_win", "5", "-dim", "64", "-slide_stride", "1",
+                     "-topk", "5", "-random_seed", "5", "-epoch", "2", "-val_ratio", "0.2", "-save_path_pattern", "msl",
+                     "-out_layer_inter_dim", "128"])
+    assert 0.0 <= info[0] <= 1.0 and len(os.listdir(tmp_path / "pretrained" / "msl")) == 1
+    assert "F1 score:" in capsys.readouterr().out
