@@ -150,15 +150,17 @@ def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
              gnn.bias.data_ptr(), emb.data_ptr(), c.bn1.data_ptr(), c.bn2.data_ptr(), lin.weight.data_ptr(),
              lin.bias.data_ptr())
     esz = 2 if storage == "bf16" else 4
-    name = "gdn_forward_fused_bf16" if storage == "bf16" else "gdn_forward_fused"
-    xs = x.bfloat16() if storage == "bf16" else x
+    bf16 = storage == "bf16"
+    name = "gdn_forward_fused_plan (" + ("bf16" if bf16 else "fp32") + " storage)"
+    plan = model._plan(c, bf16)              # per-launch constants precomputed once (include/gdn_hip.h "plans")
+    xs = x.bfloat16() if bf16 else x
     xstride, pstride = N_SENSORS * WINDOW * esz, N_SENSORS * 4
     nslots = max(1, x.shape[0] // batch)
 
     def launch(i):          # raw C-ABI call: host cost per launch stays below the kernel's duration
         s = (i % nslots) * batch
-        _lib.call(name, xs.data_ptr() + s * xstride, *fixed, batch, N_SENSORS, WINDOW, DIM, TOPK,
-                  pred.data_ptr() + s * pstride, st)
+        _lib.call("gdn_forward_fused_plan", xs.data_ptr() + s * xstride, plan.data_ptr(), batch, N_SENSORS, WINDOW, DIM,
+                  TOPK, int(bf16), pred.data_ptr() + s * pstride, st)
     for i in range(3):
         launch(i)
     mean_us, med_us = event_time_launches(launch, launches)

@@ -391,14 +391,58 @@ __device__ __forceinline__ void compute_tables(const DArgs& a, float* dst) {
   }
 }
 
+// The plan also ORDERS each lane's list slots.  A lane may visit its SL slots in any order (softmax and the
+// scatter do not care), and the order decides which LDS banks the 32 lanes of a half-wave hit together in
+// step q: the s_j gather (ds_read_b32) and, twice per window, the scatter into the dense alpha image
+// (ds_write_b16) — with the lists in rank order those were 30 % of the kernel's LDS cycles
+// (SQ_LDS_BANK_CONFLICT, profiles/r02_sq_counters_*).  Greedy, once per plan: step by step, lane by lane,
+// take the unused slot whose banks are least loaded so far in this step.
 template <int NT, int DC, int WK, int SL, int FMT>
 __global__ __launch_bounds__(64 * NT) void gdn_dense_plan_kernel(const DArgs a, unsigned* plan) {
   using K = LaneConsts<NT, DC, WK, SL, FMT>;
+  constexpr int T = 64 * NT;
+  __shared__ int s_sj[T][SL], s_sc[T][SL];
+  __shared__ unsigned char s_perm[T][SL];
   K k;
   compute_lane_consts(a, k);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < SL; ++q) {
+    s_sj[tid][q] = k.sjoff[q];
+    s_sc[tid][q] = k.scoff[q];
+  }
+  __syncthreads();
+  if ((tid & 31) == 0) {
+    unsigned used[32];
+    for (int l = 0; l < 32; ++l) used[l] = 0;
+    for (int step = 0; step < SL; ++step) {
+      unsigned char cw[32], cr[32];
+      for (int i = 0; i < 32; ++i) cw[i] = cr[i] = 0;
+      for (int l = 0; l < 32; ++l) {
+        int best = -1, best_cost = 1 << 30;
+        for (int q = 0; q < SL; ++q) {
+          if (used[l] >> q & 1u) continue;
+          const int bw = (s_sc[tid + l][q] >> 2) & 31, br = (s_sj[tid + l][q] >> 2) & 31;
+          // a second writer on a bank is free (2-way ds_write), a third costs; the scatter runs twice per window
+          const int cost = 2 * (cw[bw] >= 1 ? 1 + 4 * (cw[bw] - 1) : 0) + (cr[br] >= 1 ? 1 + 4 * (cr[br] - 1) : 0);
+          if (cost < best_cost) { best_cost = cost; best = q; }
+        }
+        used[l] |= 1u << best;
+        s_perm[tid + l][step] = (unsigned char)best;
+        ++cw[(s_sc[tid + l][best] >> 2) & 31];
+        ++cr[(s_sj[tid + l][best] >> 2) & 31];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SL; ++q) {
+    k.sjoff[q] = s_sj[tid][s_perm[tid][q]];
+    k.scoff[q] = s_sc[tid][s_perm[tid][q]];
+  }
   compute_tables<NT, DC>(a, reinterpret_cast<float*>(plan));
   unsigned* lanes = plan + K::TABLE_WORDS;
-  k.each_word([&](int i, unsigned& wd) { lanes[i * (64 * NT) + threadIdx.x] = wd; });
+  k.each_word([&](int i, unsigned& wd) { lanes[i * T + threadIdx.x] = wd; });
 }
 
 template <int NT, int DC, int WK, int SL, int FMT>

@@ -108,8 +108,9 @@ def test_dense_kernels_are_deterministic_and_alpha_does_not_change_z(shape, gpu_
 @pytest.mark.parametrize("bf16", [False, True])
 def test_planned_launch_equals_the_plain_entry_point(bf16, gpu_device):
     """gdn_forward_fused_plan (constants precomputed by gdn_fused_plan_build, what GDN.forward uses) against
-    gdn_forward_fused / gdn_forward_fused_bf16 (constants computed in every workgroup's prologue): same bits;
-    and the plan follows the parameters (rebuilt after an update)."""
+    gdn_forward_fused / gdn_forward_fused_bf16 (constants computed in every workgroup's prologue): the same
+    results up to the summation order of the softmax denominator (the plan also reorders each lane's list
+    slots to spread LDS banks); and the plan follows the parameters (rebuilt after an update)."""
     from gdn_amd import ops
     shape = dict(b=300, n=127, w=15, k=30)
     model, _p, x = setup(shape, gpu_device)
@@ -121,7 +122,7 @@ def test_planned_launch_equals_the_plain_entry_point(bf16, gpu_device):
     assert c.plans[bf16] is not None
     plain = ops.forward_fused(xd, gnn.lin.weight, c.terms, c.graph, gnn.bias, model.embedding.weight, c.bn1, c.bn2,
                               lin.weight, lin.bias)
-    assert torch.equal(planned, plain)
+    np.testing.assert_allclose(planned.cpu().numpy(), plain.cpu().numpy(), atol=2e-7, rtol=0)
     with torch.no_grad():
         gnn.lin.weight.mul_(1.25)                      # version bump -> constants and plan are rebuilt
         again = model(xd, None)
@@ -129,7 +130,7 @@ def test_planned_launch_equals_the_plain_entry_point(bf16, gpu_device):
     c2 = model._constants()
     plain2 = ops.forward_fused(xd, gnn.lin.weight, c2.terms, c2.graph, gnn.bias, model.embedding.weight, c2.bn1,
                                c2.bn2, lin.weight, lin.bias)
-    assert torch.equal(again, plain2)
+    np.testing.assert_allclose(again.cpu().numpy(), plain2.cpu().numpy(), atol=2e-7, rtol=0)
 
 
 def test_valu_and_dense_fused_paths_agree(gpu_device):

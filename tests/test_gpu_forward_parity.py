@@ -330,5 +330,6 @@ def test_integration_md_ctypes_stub_runs(gpu_device):
         want = model(x, None)
         got = types.MethodType(ns["forward"], model)(x, None)
     torch.cuda.synchronize()
-    assert torch.equal(got, want)
+    # (the packaged forward goes through a plan, which reorders each lane's list slots: same numbers to rounding)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-7, rtol=0)
     assert torch.equal(model.learned_graph, model._constants().graph.topk)

@@ -40,10 +40,14 @@ def timing(b):
     out = torch.empty((b, n), device=dev)
     c = model._constants()
     ptrs = c.fused_args[0]
+    plan = model._plan(c, False)
     st = torch.cuda.current_stream().cuda_stream
 
     def launch():
-        _lib.call("gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(), st)
+        if plan is not None:
+            _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, 0, out.data_ptr(), st)
+        else:
+            _lib.call("gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(), st)
     for _ in range(200):
         launch()
     torch.cuda.synchronize()
