@@ -48,15 +48,22 @@ __global__ __launch_bounds__(256) void gdn_graph_kernel(
   const int i = blockIdx.x;
   const float* ei = emb + (size_t)i * d;
 
+  // rows are read as float4 (d is a multiple of 4: 16 B aligned rows) — with scalar loads a thread issued d
+  // dependent L2 round trips and the kernel took 17 us of a 230 us training step; the k-ordered fmaf chains
+  // (and therefore every cosine bit) are unchanged
   float ni2 = 0.f;
   for (int t = 0; t < d; ++t) ni2 = fmaf(ei[t], ei[t], ni2);
   const float ni = sqrtf(ni2);
+  const float4* ei4 = reinterpret_cast<const float4*>(ei);
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const float* ej = emb + (size_t)j * d;
+    const float4* ej4 = reinterpret_cast<const float4*>(emb + (size_t)j * d);
     float dot = 0.f, nj2 = 0.f;
-    for (int t = 0; t < d; ++t) {
-      dot = fmaf(ei[t], ej[t], dot);
-      nj2 = fmaf(ej[t], ej[t], nj2);
+    for (int t = 0; t < d / 4; ++t) {
+      const float4 a4 = ei4[t], b4 = ej4[t];
+      dot = fmaf(a4.x, b4.x, dot); nj2 = fmaf(b4.x, b4.x, nj2);
+      dot = fmaf(a4.y, b4.y, dot); nj2 = fmaf(b4.y, b4.y, nj2);
+      dot = fmaf(a4.z, b4.z, dot); nj2 = fmaf(b4.z, b4.z, nj2);
+      dot = fmaf(a4.w, b4.w, dot); nj2 = fmaf(b4.w, b4.w, nj2);
     }
     const float c = dot / (ni * sqrtf(nj2));  // GDN.py:152 has no epsilon: zero rows give NaN
     cosrow[j] = c;
@@ -143,7 +150,7 @@ __global__ void gdn_bn_fold_kernel(const float* __restrict__ weight, const float
 extern "C" int gdn_topk_graph(const float* emb, int n, int d, int k, int64_t* topk_idx, uint16_t* nbr,
                               int32_t* deg, float* cos_out, void* stream) {
   if (!emb || !topk_idx || !nbr || !deg || n <= 0 || d <= 0 || k <= 0) return GDN_ERR_ARG;
-  if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
+  if (k > n || n > 4096 || k + 1 > 1024 || (d & 3)) return GDN_ERR_UNSUPPORTED;
   const int pitch = gdn_nbr_pitch(k);
   hipLaunchKernelGGL(gdn_graph_kernel, dim3(n), dim3(256), 2 * n * sizeof(float), (hipStream_t)stream,
                      emb, n, d, k, pitch, topk_idx, nbr, deg, cos_out);

@@ -616,10 +616,16 @@ __global__ __launch_bounds__(1024) void gdn_adam_kernel(float* __restrict__ p, f
   // scalars arrive as the Python floats torch's optimizer holds (double) and are rounded to fp32 where torch
   // rounds them: 1 - beta in double first (1 - 0.999f is 4.7e-5 off 0.001)
   const long long t = step[0] + 1;
-  const double bc1 = 1.0 - pow(beta1_d, (double)t);
-  const double bc2 = 1.0 - pow(beta2_d, (double)t);
-  const float step_size = (float)(lr_d / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
+  __shared__ float s_bias[2];
+  if (threadIdx.x == 0) {      // the two double-precision pow() once, not 1024 times
+    const double bc1 = 1.0 - pow(beta1_d, (double)t);
+    const double bc2 = 1.0 - pow(beta2_d, (double)t);
+    s_bias[0] = (float)(lr_d / bc1);
+    s_bias[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = s_bias[0];
+  const float bc2_sqrt = s_bias[1];
   const float beta2 = (float)beta2_d, omb1 = (float)(1.0 - beta1_d), omb2 = (float)(1.0 - beta2_d);
   const float eps = (float)eps_d, wd = (float)wd_d, grad_scale = (float)grad_scale_d;
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
