@@ -406,6 +406,12 @@ class SeriesEvaluator:
 
     def _launch_forward(self):
         m = self.model
+        # constants and the plan are built (when stale) HERE, on the caller's stream, before the fork: built
+        # lazily inside the first side-stream launch, the launches on the other side streams would read them
+        # unordered (first eager step after a parameter update: garbage in some windows)
+        if m.out_layer_num == 1 and not m.training:
+            src = self.series if self.series is not None else self.x
+            m._plan(m._constants(), src.dtype == torch.bfloat16)
         spans = [(s, min(self.t, s + self.batch)) for s in range(0, self.t, self.batch)]
         if self.series is not None:
             def launch(s, e):

@@ -22,6 +22,7 @@ forward on CPU tensors raises.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import torch
@@ -193,7 +194,7 @@ class OutLayer(nn.Module):
 
 
 class _EvalConstants:
-    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans", "mlp")
+    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans", "mlp", "stream", "ready")
 
 
 class GDN(nn.Module):
@@ -285,6 +286,12 @@ class GDN(nn.Module):
                 assert all(t.is_cuda and t.is_contiguous() for t in ts)
                 d, w = gnn.lin.weight.shape
                 c.fused_args = (tuple(t.data_ptr() for t in ts), emb.shape[0], w, d, c.graph.k)
+        if emb.is_cuda:     # built on this stream: launches on another stream order themselves behind it
+            c.stream = torch.cuda.current_stream()
+            c.ready = torch.cuda.Event()
+            c.ready.record(c.stream)
+        else:
+            c.stream = c.ready = None
         self._consts = c
         return c
 
@@ -298,7 +305,10 @@ class GDN(nn.Module):
             raise ValueError(f"expected data of shape [B, {n}, {w}], got {tuple(x.shape)}")
         bf16 = x.dtype == torch.bfloat16
         plan = self._plan(c, bf16)
-        st = torch.cuda.current_stream().cuda_stream
+        cur = torch.cuda.current_stream()
+        if c.ready is not None and cur != c.stream and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(c.ready)      # (a capture is preceded by a warm-up + synchronize: nothing to wait for)
+        st = cur.cuda_stream
         if plan is not None:
             _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, int(bf16),
                       out.data_ptr(), st)
@@ -313,8 +323,12 @@ class GDN(nn.Module):
         if bf16 not in c.plans:
             gnn = self.gnn_layers[0].gnn
             lin = self.out_layer.mlp[0]
-            c.plans[bf16] = ops.fused_plan(gnn.lin.weight, c.terms, c.graph, gnn.bias, self.embedding.weight,
-                                           c.bn1, c.bn2, lin.weight, lin.bias, bf16_storage=bf16)
+            with torch.cuda.stream(c.stream) if c.stream is not None else contextlib.nullcontext():
+                c.plans[bf16] = ops.fused_plan(gnn.lin.weight, c.terms, c.graph, gnn.bias, self.embedding.weight,
+                                               c.bn1, c.bn2, lin.weight, lin.bias, bf16_storage=bf16)
+                if c.ready is not None:
+                    c.ready = torch.cuda.Event()
+                    c.ready.record(c.stream)
         return c.plans[bf16]
 
     # ------------------------------------------------------------------ forward
