@@ -140,7 +140,20 @@ struct Args {
   float* z;         // [BN, d]   (MODE_ATTN)
   float* alpha;     // [BN, pitch] or null
   float* out;       // [BN]      (MODE_FUSED)
+  int x_bf16;       // bf16 storage: x holds bfloat16 bits, the projected tile is rounded to bf16
 };
+
+// x element idx of a window whose first element is `elems` past a.x, for either storage type
+__device__ __forceinline__ const float* x_base(const Args& a, size_t elems) {
+  return a.x_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(a.x) + elems) : a.x + elems;
+}
+__device__ __forceinline__ float x_elem(const Args& a, const float* base, size_t idx) {
+  return a.x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(base)[idx] << 16) : base[idx];
+}
+__device__ __forceinline__ float round_to_bf16(float v) {   // round to nearest even, as torch's .bfloat16()
+  const unsigned u = __float_as_uint(v);
+  return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+}
 
 // ------------------------------------------------------------------ projection phase
 // lin.weight lives in LDS for the whole workgroup, permuted so that a lane fetches its
@@ -254,6 +267,10 @@ __device__ __forceinline__ void project_chunk(const Plan& pl, const Args& a, flo
     for (int c = 0; c < WCH; ++c)
 #pragma unroll
       for (int v = 0; v < G::VEC; ++v) acc.v[v] = fmaf(xr[c], wl[v][c], acc.v[v]);
+    if (a.x_bf16 && last) {
+#pragma unroll
+      for (int v = 0; v < G::VEC; ++v) acc.v[v] = round_to_bf16(acc.v[v]);
+    }
     st_pack<G::VEC>(xl + (size_t)row * D + d0, acc);
     if (TO_GLOBAL && last)
       st_pack<G::VEC>(a.xlin_out + ((size_t)b * pl.n + row) * pl.dfull + GDN_COL0(D) + d0, acc);
@@ -581,14 +598,14 @@ struct XFlat {
 // builds x[b] = data[:, b : b+w] on the host, a w-fold redundant copy — neighbouring windows share
 // all but one column, so the series is fetched from HBM once).  One code path, no branch.
 template <int XU>
-__device__ __forceinline__ void xflat_load(const float* src, int row_stride, int cnt, int w, float inv_w,
-                                           XFlat<XU>& r) {
+__device__ __forceinline__ void xflat_load(const Args& a, const float* src, int row_stride, int cnt, int w,
+                                           float inv_w, XFlat<XU>& r) {
 #pragma unroll
   for (int u = 0; u < XU; ++u) {   // unconditional, clamped: stays in registers
     const int t = min((int)threadIdx.x + u * (int)blockDim.x, cnt - 1);
     const int row = (int)((t + 0.5f) * inv_w);   // exact for t < 2^16, w <= 64
     // 32-bit, window-invariant offset from a wave-uniform base: one VGPR per element
-    r.v[u] = src[(unsigned int)(row * row_stride + (t - row * w))];
+    r.v[u] = x_elem(a, src, (unsigned int)(row * row_stride + (t - row * w)));
   }
 }
 
@@ -657,7 +674,7 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
       for (int r = 0; r < 16; ++r) {
         const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < pl.n) {
-          xl[row * D + cb * 32 + l32] = acc[r];
+          xl[row * D + cb * 32 + l32] = a.x_bf16 ? round_to_bf16(acc[r]) : acc[r];
           if constexpr (MODE == MODE_PROJECT)
             a.xlin_out[((size_t)b * pl.n + row) * pl.dfull + GDN_COL0(D) + cb * 32 + l32] = acc[r];
         }
@@ -687,8 +704,10 @@ __device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, 
   XFlat<XU> xr;
   const int row_stride = a.series_len > 0 ? a.series_len : pl.w;
   const size_t win_stride = a.series_len > 0 ? 1 : (size_t)cnt;   // distance between windows b, b+1
-  const float* x0 = a.x + (a.series_len > 0 ? a.series_first : 0);
-  auto load_window = [&](int bb) { xflat_load<XU>(x0 + (size_t)bb * win_stride, row_stride, cnt, pl.w, inv_w, xr); };
+  const size_t first = a.series_len > 0 ? a.series_first : 0;
+  auto load_window = [&](int bb) {
+    xflat_load<XU>(a, x_base(a, first + (size_t)bb * win_stride), row_stride, cnt, pl.w, inv_w, xr);
+  };
   load_window(blockIdx.x);
   __syncthreads();   // zero fill done before the first store
   xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
@@ -714,7 +733,7 @@ struct XRegs {
   float v[8];
 };
 
-__device__ __forceinline__ void stage_x_load(const Plan& pl, const float* xg, XRegs& xr) {
+__device__ __forceinline__ void stage_x_load(const Plan& pl, const Args& a, const float* xg, XRegs& xr) {
   const int c = threadIdx.x & (pl.wp - 1);
   const int rstep = blockDim.x / pl.wp;
   const int r = threadIdx.x / pl.wp;
@@ -723,7 +742,7 @@ __device__ __forceinline__ void stage_x_load(const Plan& pl, const float* xg, XR
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int rr = min(r + u * rstep, pl.n - 1);
-    const float t = xg[(size_t)rr * pl.w + cc];   // unconditional (clamped) load: stays in registers
+    const float t = x_elem(a, xg, (size_t)rr * pl.w + cc);   // unconditional (clamped) load: stays in registers
     xr.v[u] = live ? t : 0.f;
   }
 }
@@ -740,11 +759,11 @@ __device__ __forceinline__ void stage_x_store(const Plan& pl, float* xs, const X
 }
 
 // General form: rows [r0, r1), any wp.
-__device__ __forceinline__ void stage_x(const Plan& pl, const float* xg, float* xs, int r0, int r1) {
+__device__ __forceinline__ void stage_x(const Plan& pl, const Args& a, const float* xg, float* xs, int r0, int r1) {
   const int cnt = (r1 - r0) * pl.wp;
   for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
     const int r = t / pl.wp, c = t - r * pl.wp;
-    xs[t] = c < pl.w ? xg[(size_t)(r0 + r) * pl.w + c] : 0.f;
+    xs[t] = c < pl.w ? x_elem(a, xg, (size_t)(r0 + r) * pl.w + c) : 0.f;
   }
 }
 
@@ -858,12 +877,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
     const bool fast = nch == 1 && pl.xrows >= pl.n && pl.n <= 8 * (int)(blockDim.x / pl.wp);
     if (fast) {
       XRegs xr;
-      stage_x_load(pl, a.x + (size_t)blockIdx.x * pl.n * pl.w, xr);
+      stage_x_load(pl, a, x_base(a, (size_t)blockIdx.x * pl.n * pl.w), xr);
       for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
         stage_x_store(pl, xs, xr);
         __syncthreads();
         const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round: harmless re-read
-        stage_x_load(pl, a.x + (size_t)nb * pl.n * pl.w, xr);   // lands under the math
+        stage_x_load(pl, a, x_base(a, (size_t)nb * pl.n * pl.w), xr);   // lands under the math
         {
           float wl[G::VEC][WCH];
           load_lane_weights<D, WCH>(pl, a, wlds, 0, wl);
@@ -879,7 +898,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
       for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
         for (int r0 = 0; r0 < pl.n; r0 += pl.xrows) {
           const int r1 = min(pl.n, r0 + pl.xrows);
-          stage_x(pl, a.x + (size_t)b * pl.n * pl.w, xs, r0, r1);
+          stage_x(pl, a, x_base(a, (size_t)b * pl.n * pl.w), xs, r0, r1);
           __syncthreads();
           for (int wc = 0; wc < nch; ++wc) {
             // the weight block is re-read from LDS every time instead of living in 64 VGPRs
@@ -1152,6 +1171,26 @@ extern "C" int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const
   return dispatch_window<MODE_ATTN>(pl, a, threads, (hipStream_t)stream);
 }
 
+namespace {
+// sparse-gather kernel for the shapes the dense kernels do not cover (x_bf16: bf16 storage of x and xlin)
+int fused_gather(const void* x, int x_bf16, const float* lin_w, const float* node_terms, const uint16_t* nbr,
+                 const int32_t* deg, const float* gnn_bias, const float* emb, const float* bn1_affine,
+                 const float* bn2_affine, const float* out_w, const float* out_b, int batch, int n, int w,
+                 int d, int k, float* out, void* stream) {
+  Plan pl; int threads;
+  const int rc = make_plan(MODE_FUSED, batch, n, w, d, k, &pl, &threads);
+  if (rc != GDN_OK) return rc;
+  Args a = {};
+  a.x = static_cast<const float*>(x); a.x_bf16 = x_bf16; a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.deg = deg;
+  a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;
+  a.out_w = out_w; a.out_b = out_b; a.out = out;
+  if (pl.nslices > 1 &&   // the slices add their partial head outputs into `out`
+      hipMemsetAsync(out, 0, (size_t)batch * n * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return GDN_ERR_LAUNCH;
+  return dispatch_window<MODE_FUSED>(pl, a, threads, (hipStream_t)stream);
+}
+}  // namespace
+
 extern "C" int gdn_forward_fused(const float* x, const float* lin_w, const float* node_terms,
                                  const uint16_t* nbr, const int32_t* deg, const float* gnn_bias,
                                  const float* emb, const float* bn1_affine, const float* bn2_affine,
@@ -1163,17 +1202,8 @@ extern "C" int gdn_forward_fused(const float* x, const float* lin_w, const float
   if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, w, d, k))
     return gdn_dense_forward_fused(x, 0, 0, 0, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine, bn2_affine,
                                    out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
-  Plan pl; int threads;
-  const int rc = make_plan(MODE_FUSED, batch, n, w, d, k, &pl, &threads);
-  if (rc != GDN_OK) return rc;
-  Args a = {};
-  a.x = x; a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.deg = deg;
-  a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;
-  a.out_w = out_w; a.out_b = out_b; a.out = out;
-  if (pl.nslices > 1 &&   // the slices add their partial head outputs into `out`
-      hipMemsetAsync(out, 0, (size_t)batch * n * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    return GDN_ERR_LAUNCH;
-  return dispatch_window<MODE_FUSED>(pl, a, threads, (hipStream_t)stream);
+  return fused_gather(x, 0, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
+                      batch, n, w, d, k, out, stream);
 }
 
 extern "C" int gdn_forward_fused_series(const float* series, int series_len, int first, const float* lin_w,
@@ -1258,6 +1288,9 @@ extern "C" int gdn_forward_fused_bf16(const uint16_t* x, const float* lin_w, con
   if (!x || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine || !bn2_affine ||
       !out_w || !out_b || !out || batch <= 0)
     return GDN_ERR_ARG;
-  return gdn_dense_forward_fused(x, 1, 0, 0, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine, bn2_affine,
-                                 out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
+  if (gdn_use_dense_path() && gdn_dense_supported(n, w, d, k))
+    return gdn_dense_forward_fused(x, 1, 0, 0, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine, bn2_affine,
+                                   out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
+  return fused_gather(x, 1, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
+                      batch, n, w, d, k, out, stream);
 }

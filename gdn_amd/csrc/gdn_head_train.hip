@@ -62,6 +62,8 @@ struct HeadArgs {
   double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
   float* demb_part;      // backward: [EMB_PARTS][n][d] per-part sums of d_emb
   float *out, *d_z;
+  float* act;            // forward, MLP head (out_layer_num > 1): the [BN, d] activation after dropout instead of `out`
+  const float* d_act;    // backward, MLP head: its gradient instead of d_out (x) lin.weight
   int batch, n;
   float eps1, eps2;
   int chunks, parts;     // grid = chunks (of SLOTS sensors) x parts (of the batch)
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   if constexpr (MODE >= H_STAT2) bn1 = bn_cols(tot, tot + D, rows, a.eps1, a.g1, a.b1, c0);
   if constexpr (MODE >= H_OUT) bn2 = bn_cols(tot + 2 * D, tot + 3 * D, rows, a.eps2, a.g2, a.b2, c0);
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (MODE >= H_OUT) ld4(a.w + c0, w4);
+  if (MODE >= H_OUT && a.w) ld4(a.w + c0, w4);
   float m2a[4] = {}, m2b[4] = {}, m1a[4] = {}, m1b[4] = {};
   if constexpr (MODE >= H_BWD1) {
 #pragma unroll
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   }
   double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
   double acc_s = 0.0;
-  const float bias_o = (MODE == H_OUT) ? a.bo[0] : 0.f;
+  const float bias_o = (MODE == H_OUT && a.bo) ? a.bo[0] : 0.f;
   unsigned rng_k0 = 0, rng_k1 = 0;
   if (MODE >= H_OUT && a.rng) {
     const unsigned long long seed = (unsigned long long)a.rng[0], step = (unsigned long long)a.rng[1];
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
 
   if (live) {
     for (int bq = b0; bq < b1; bq += U) {
-      float zq[U][4], mq[U][4], goq[U];
+      float zq[U][4], mq[U][4], goq[U], gaq[U][4];
 #pragma unroll
       for (int u = 0; u < U; ++u) {                     // all loads of the round first
         const int b = min(bq + u, b1 - 1);
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) mq[u][v] = gdn_mix32(e0 + v, rng_k0, rng_k1) >= a.rng_threshold ? a.keep_scale : 0.f;
         }
-        goq[u] = MODE >= H_BWD2 ? a.d_out[row] : 0.f;
+        goq[u] = (MODE >= H_BWD2 && a.d_out) ? a.d_out[row] : 0.f;
+        gaq[u][0] = gaq[u][1] = gaq[u][2] = gaq[u][3] = 0.f;
+        if (MODE >= H_BWD2 && a.d_act) ld4(a.d_act + row * D + c0, gaq[u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -262,6 +266,11 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
           a2[v] = fmaxf(y2[v], 0.f);
         }
         if constexpr (MODE == H_OUT) {
+          if (a.act) {   // MLP head: hand the dropped-out activation to the OutLayer (models/GDN.py:182-183)
+            *reinterpret_cast<float4*>(a.act + row * D + c0) =
+                make_float4(a2[0] * m[0], a2[1] * m[1], a2[2] * m[2], a2[3] * m[3]);
+            continue;
+          }
           float part_o = 0.f;
 #pragma unroll
           for (int v = 0; v < 4; ++v) part_o = fmaf(a2[v] * m[v], w4[v], part_o);
@@ -274,7 +283,8 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
         float dy2[4], x2h[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          dy2[v] = y2[v] > 0.f ? go * w4[v] * m[v] : 0.f;
+          const float gh = a.d_act ? gaq[u][v] : go * w4[v];   // gradient of the head's [BN, d] activation
+          dy2[v] = y2[v] > 0.f ? gh * m[v] : 0.f;
           x2h[v] = (h1[v] - bn2.mu[v]) * bn2.is[v];
         }
         if constexpr (MODE == H_BWD2) {
@@ -354,8 +364,8 @@ __global__ void gdn_head_finish_kernel(const double* __restrict__ ws, const floa
     d_bn2_w[t] = (float)repl_sum(ws + d + t, 6 * d);
     d_bn1_b[t] = (float)repl_sum(ws + 2 * d + t, 6 * d);
     d_bn1_w[t] = (float)repl_sum(ws + 3 * d + t, 6 * d);
-    d_lin_w[t] = (float)repl_sum(ws + 4 * d + t, 6 * d);
-    if (t == 0) d_lin_b[0] = (float)repl_sum(ws + 5 * d, 6 * d);
+    if (d_lin_w) d_lin_w[t] = (float)repl_sum(ws + 4 * d + t, 6 * d);
+    if (t == 0 && d_lin_b) d_lin_b[0] = (float)repl_sum(ws + 5 * d, 6 * d);
   }
   if (t < n * d) {
     double s = 0.0;
@@ -471,9 +481,9 @@ static int head_train_fwd_impl(const float* z, const float* emb, const float* bn
                                   float eps2, float momentum1, float momentum2, float* running_mean1,
                                   float* running_var1, long long* batches1, float* running_mean2,
                                   float* running_var2, long long* batches2, double* stats, float* out,
-                                  void* stream) {
-  if (!z || !emb || !bn1_w || !bn1_b || !bn2_w || !bn2_b || !lin_w || !lin_b || !stats || !out)
-    return GDN_ERR_ARG;
+                                  void* stream, float* act = nullptr) {
+  if (!z || !emb || !bn1_w || !bn1_b || !bn2_w || !bn2_b || !stats) return GDN_ERR_ARG;
+  if (act ? (lin_w || lin_b || out) : (!lin_w || !lin_b || !out)) return GDN_ERR_ARG;
   if (!head_shape_ok(batch, n, d)) return GDN_ERR_ARG;   // torch: "Expected more than 1 value per channel"
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -483,7 +493,7 @@ static int head_train_fwd_impl(const float* z, const float* emb, const float* bn
   if (!mask && !keep && rng && p_drop > 0.f) {
     a.rng = rng; a.rng_threshold = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
   }
-  a.fstats = stats; a.acc = stats; a.out = out; a.batch = batch; a.n = n;
+  a.fstats = stats; a.acc = stats; a.out = out; a.act = act; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
   a.run = {running_mean1, running_var1, running_mean2, running_var2, batches1, batches2, momentum1, momentum2};
   if (hipMemsetAsync(stats, 0, (size_t)GDN_HEAD_REPL * 4 * d * sizeof(double), st) != hipSuccess)
@@ -537,10 +547,12 @@ static int head_train_bwd_impl(const float* d_out, const float* z, const float* 
                                   const double* stats, int batch,
                                   int n, int d, float eps1, float eps2, double* workspace, float* d_z,
                                   float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
-                                  float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream) {
-  if (!d_out || !z || !emb || !bn1_w || !bn1_b || !bn2_w || !bn2_b || !lin_w || !stats || !workspace ||
-      !d_z || !d_emb || !d_bn1_w || !d_bn1_b || !d_bn2_w || !d_bn2_b || !d_lin_w || !d_lin_b)
+                                  float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream,
+                                  const float* d_act = nullptr) {
+  if (!z || !emb || !bn1_w || !bn1_b || !bn2_w || !bn2_b || !stats || !workspace ||
+      !d_z || !d_emb || !d_bn1_w || !d_bn1_b || !d_bn2_w || !d_bn2_b)
     return GDN_ERR_ARG;
+  if (d_act ? (d_out || lin_w || d_lin_w || d_lin_b) : (!d_out || !lin_w || !d_lin_w || !d_lin_b)) return GDN_ERR_ARG;
   if (!head_shape_ok(batch, n, d)) return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -550,7 +562,7 @@ static int head_train_bwd_impl(const float* d_out, const float* z, const float* 
   if (!mask && !keep && rng && p_drop > 0.f) {
     a.rng = rng; a.rng_threshold = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
   }
-  a.d_out = d_out; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
+  a.d_out = d_out; a.d_act = d_act; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
   const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
   a.demb_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sums_bytes);
@@ -597,6 +609,33 @@ extern "C" int gdn_head_train_bwd_rng(const float* d_out, const float* z, const 
   return head_train_bwd_impl(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, nullptr, nullptr, 1.f, rng_seed_step,
                              p_drop, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b,
                              d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, stream);
+}
+
+// MLP head (out_layer_num > 1, models/GDN.py:27-56): the same passes, ending at the [BN, d] activation
+// after dropout (forward) / starting from its gradient (backward) instead of the fused Linear(d -> 1).
+extern "C" int gdn_head_train_fwd_act(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                                      const float* bn2_w, const float* bn2_b, const float* mask,
+                                      const uint8_t* keep, float keep_scale, int batch, int n, int d, float eps1,
+                                      float eps2, float momentum1, float momentum2, float* running_mean1,
+                                      float* running_var1, long long* batches1, float* running_mean2,
+                                      float* running_var2, long long* batches2, double* stats, float* act,
+                                      void* stream) {
+  if (!act) return GDN_ERR_ARG;
+  return head_train_fwd_impl(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, nullptr, mask, keep, keep_scale, nullptr,
+                             0.f, batch, n, d, eps1, eps2, momentum1, momentum2, running_mean1, running_var1,
+                             batches1, running_mean2, running_var2, batches2, stats, nullptr, stream, act);
+}
+
+extern "C" int gdn_head_train_bwd_act(const float* d_act, const float* z, const float* emb, const float* bn1_w,
+                                      const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                                      const float* mask, const uint8_t* keep, float keep_scale,
+                                      const double* stats, int batch, int n, int d, float eps1, float eps2,
+                                      double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
+                                      float* d_bn2_w, float* d_bn2_b, void* stream) {
+  if (!d_act) return GDN_ERR_ARG;
+  return head_train_bwd_impl(nullptr, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, mask, keep, keep_scale, nullptr,
+                             0.f, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b,
+                             d_bn2_w, d_bn2_b, nullptr, nullptr, stream, d_act);
 }
 
 // ---- Adam over ONE flat parameter buffer (reference train.py:31,73: torch.optim.Adam(lr, weight_decay)) ----

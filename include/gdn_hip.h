@@ -264,8 +264,17 @@ int gdn_forward_fused_series_plan(const float* series, int series_len, int first
  *   z     = sum_j alpha_ij xlin_j + bias in fp32; gdn_attn_aggregate_fwd_bf16 stores bf16(z),
  *           gdn_forward_fused_bf16 keeps z on chip in fp32;
  *   head  as gdn_head_fwd.
- * Matrix-core path only: n <= 127, d = 64, w <= 32, k <= 63; other shapes return
- * GDN_ERR_UNSUPPORTED.                                                                   */
+ * The three staged entry points: matrix-core path only (n <= 127, d = 64, w <= 32,
+ * k <= 63; other shapes return GDN_ERR_UNSUPPORTED).  gdn_forward_fused_bf16 takes every
+ * shape gdn_forward_fused takes: outside the matrix-core path the fp32 row-gather kernel
+ * reads the bf16 windows and rounds its LDS-resident projected tile to bf16 (configs[4]:
+ * 512 sensors, top-k 64, W = 30).
+ * RANGE of the matrix-core kernels (fp32 and bf16 storage alike): operands travel as 16-bit
+ * terms, x and the BatchNorm-folded features 8*(scale1*xlin + shift) must stay below 65504
+ * in magnitude — true for the MinMax / standardised sensor data the reference trains on
+ * (main.py:60-75); beyond it a 16-bit term overflows and the results are undefined (inf/NaN,
+ * which the ReLUs may turn into 0).  GDN_FUSED_PATH=valu in the environment selects the fp32
+ * row-gather kernels, which have fp32 range, for such data.                              */
 int gdn_project_fwd_bf16(const uint16_t* x, const float* lin_w, const float* node_terms,
                          int batch, int n, int w, int d,
                          uint16_t* xlin, float* s_i, float* s_j, void* stream);

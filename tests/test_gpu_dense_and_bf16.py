@@ -223,11 +223,36 @@ def test_bf16_storage_at_baseline_config2_batch_512(gpu_device):
     np.testing.assert_allclose(out.cpu().numpy(), data["eval_out"], atol=2e-3, rtol=0)
 
 
-def test_bf16_storage_refuses_shapes_outside_the_matrix_core_path(gpu_device):
+@pytest.mark.parametrize("n,w,k,d,b", [(512, 30, 64, 64, 6), (300, 12, 20, 64, 5), (127, 15, 30, 128, 9),
+                                       (200, 40, 90, 32, 4)],
+                         ids=["config4_n512_k64_w30", "n300_w12_k20", "n127_d128", "n200_w40_k90_d32"])
+def test_bf16_storage_fused_forward_on_the_gather_path(n, w, k, d, b, gpu_device):
+    """Shapes the matrix-core kernels do not take (n > 127, d != 64, w > 32): the fp32 row-gather kernel reads
+    bf16 windows and rounds the LDS-resident projected tile to bf16 — the same storage semantics, the
+    oracle's rounding point exactly.  First case = BASELINE configs[4] as worded (512 sensors, top-k 64,
+    W=30, bf16)."""
+    model = random_params(n, w, k, d, seed=4)
+    p = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    xb = torch.rand((b, n, w), generator=torch.Generator().manual_seed(8)).bfloat16()
+    with torch.no_grad():
+        out = model(xb.to(gpu_device), None)
+        out32 = model(xb.float().to(gpu_device), None)
+    graph = model.learned_graph.cpu()
+    ref = gdn_oracle.forward(f64_params(p), xb.double(), k, graph=graph, storage="bf16")
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4, rtol=0)
+    assert not torch.equal(out, out32)                       # the tile really was rounded
+    assert float((out - out32).abs().max()) < 5e-3
+
+
+def test_bf16_staged_kernels_refuse_shapes_outside_the_matrix_core_path(gpu_device):
+    """The staged bf16 entry points (bf16 xlin / z in HBM) exist for the matrix-core shapes only."""
+    from gdn_amd import ops
     from gdn_amd._lib import GdnHipError
     model = random_params(300, 12, 20, 64, seed=1).to(gpu_device).eval()
+    c = model._constants()
     with pytest.raises(GdnHipError, match="UNSUPPORTED"):
-        model(torch.rand((2, 300, 12), device=gpu_device).bfloat16(), None)
+        ops.project_fwd(torch.rand((2, 300, 12), device=gpu_device).bfloat16(), model.gnn_layers[0].gnn.lin.weight, c.terms)
 
 
 @pytest.mark.parametrize("cfg", [dict(n=127, w=15, k=30, d=64, hidden=256, layers=2, b=9),
