@@ -615,27 +615,30 @@ extern "C" int gdn_head_train_bwd_rng(const float* d_out, const float* z, const 
 // after dropout (forward) / starting from its gradient (backward) instead of the fused Linear(d -> 1).
 extern "C" int gdn_head_train_fwd_act(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
                                       const float* bn2_w, const float* bn2_b, const float* mask,
-                                      const uint8_t* keep, float keep_scale, int batch, int n, int d, float eps1,
+                                      const uint8_t* keep, float keep_scale, const long long* rng_seed_step,
+                                      float p_drop, int batch, int n, int d, float eps1,
                                       float eps2, float momentum1, float momentum2, float* running_mean1,
                                       float* running_var1, long long* batches1, float* running_mean2,
                                       float* running_var2, long long* batches2, double* stats, float* act,
                                       void* stream) {
-  if (!act) return GDN_ERR_ARG;
-  return head_train_fwd_impl(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, nullptr, mask, keep, keep_scale, nullptr,
-                             0.f, batch, n, d, eps1, eps2, momentum1, momentum2, running_mean1, running_var1,
-                             batches1, running_mean2, running_var2, batches2, stats, nullptr, stream, act);
+  if (!act || p_drop < 0.f || p_drop >= 1.f) return GDN_ERR_ARG;
+  return head_train_fwd_impl(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, nullptr, mask, keep, keep_scale,
+                             rng_seed_step, p_drop, batch, n, d, eps1, eps2, momentum1, momentum2, running_mean1,
+                             running_var1, batches1, running_mean2, running_var2, batches2, stats, nullptr, stream,
+                             act);
 }
 
 extern "C" int gdn_head_train_bwd_act(const float* d_act, const float* z, const float* emb, const float* bn1_w,
                                       const float* bn1_b, const float* bn2_w, const float* bn2_b,
                                       const float* mask, const uint8_t* keep, float keep_scale,
+                                      const long long* rng_seed_step, float p_drop,
                                       const double* stats, int batch, int n, int d, float eps1, float eps2,
                                       double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
                                       float* d_bn2_w, float* d_bn2_b, void* stream) {
-  if (!d_act) return GDN_ERR_ARG;
-  return head_train_bwd_impl(nullptr, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, mask, keep, keep_scale, nullptr,
-                             0.f, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b,
-                             d_bn2_w, d_bn2_b, nullptr, nullptr, stream, d_act);
+  if (!d_act || p_drop < 0.f || p_drop >= 1.f) return GDN_ERR_ARG;
+  return head_train_bwd_impl(nullptr, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, mask, keep, keep_scale,
+                             rng_seed_step, p_drop, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w,
+                             d_bn1_b, d_bn2_w, d_bn2_b, nullptr, nullptr, stream, d_act);
 }
 
 // ---- Adam over ONE flat parameter buffer (reference train.py:31,73: torch.optim.Adam(lr, weight_decay)) ----

@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------- column passes over [rows, H]
-// Thread = 4 consecutive columns; LPR = H/4 lanes per row (a power of two <= 64, so a row never
-// straddles a wave); a workgroup takes 256/LPR rows per round and strides over the rows.
+// Thread = 4 consecutive columns; LPR = H/4 rounded up to a power of two (<= 64, so a row never
+// straddles a wave; lanes past column H idle); a workgroup takes 256/LPR rows per round and strides
+// over the rows.
 enum { CP_OUT = 0, CP_BSTAT = 1, CP_BAPPLY = 2 };
 
 struct ColArgs {
@@ -187,28 +188,37 @@ __device__ __forceinline__ void ldf4(const float* p, float (&v)[4]) {
   v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 
+__host__ __device__ inline int col_lanes(int H) {
+  int l = 1;
+  while (l * 4 < H) l <<= 1;
+  return l;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
   __shared__ double red[256 * 4];
   const int tid = threadIdx.x;
-  const int lpr = a.H >> 2, slots = 256 / lpr;
+  const int lpr = col_lanes(a.H), slots = 256 / lpr;
   const int lr = tid % lpr, slot = tid / lpr, c0 = lr * 4;
-  float sc[4], sh[4], mu[4], is[4], wo[4] = {0.f, 0.f, 0.f, 0.f}, ma[4] = {}, mb[4] = {};
-  ldf4(a.consts + c0, sc);
-  ldf4(a.consts + a.H + c0, sh);
-  ldf4(a.consts + 2 * a.H + c0, mu);
-  ldf4(a.consts + 3 * a.H + c0, is);
-  if (a.w_o) ldf4(a.w_o + c0, wo);
-  if (MODE == CP_BAPPLY) {
-    ldf4(a.bmeans + c0, ma);
-    ldf4(a.bmeans + a.H + c0, mb);
+  const bool live = c0 < a.H;
+  float sc[4] = {}, sh[4] = {}, mu[4] = {}, is[4] = {}, wo[4] = {}, ma[4] = {}, mb[4] = {};
+  if (live) {
+    ldf4(a.consts + c0, sc);
+    ldf4(a.consts + a.H + c0, sh);
+    ldf4(a.consts + 2 * a.H + c0, mu);
+    ldf4(a.consts + 3 * a.H + c0, is);
+    if (a.w_o) ldf4(a.w_o + c0, wo);
+    if (MODE == CP_BAPPLY) {
+      ldf4(a.bmeans + c0, ma);
+      ldf4(a.bmeans + a.H + c0, mb);
+    }
   }
   const float bias_o = (MODE == CP_OUT) ? a.b_o[0] : 0.f;
   double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   double s_go = 0.0;
   for (int m = blockIdx.x * slots + slot; m < a.rows; m += gridDim.x * slots) {
-    float y[4], act[4];
-    ldf4(a.Y + (size_t)m * a.H + c0, y);
+    float y[4] = {0.f, 0.f, 0.f, 0.f}, act[4];
+    if (live) ldf4(a.Y + (size_t)m * a.H + c0, y);
 #pragma unroll
     for (int v = 0; v < 4; ++v) act[v] = fmaxf(fmaf(y[v], sc[v], sh[v]), 0.f);
     if constexpr (MODE == CP_OUT) {
@@ -221,7 +231,8 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
       float gsrc[4];
       float go = 0.f;
       if (a.dA) {
-        ldf4(a.dA + (size_t)m * a.H + c0, gsrc);
+        gsrc[0] = gsrc[1] = gsrc[2] = gsrc[3] = 0.f;
+        if (live) ldf4(a.dA + (size_t)m * a.H + c0, gsrc);
       } else {
         go = a.d_out[m];
 #pragma unroll
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
           o[v] = sc[v] * (dyh[v] - ma[v] - yh[v] * mb[v]);   // BatchNorm backward, sc = gamma * rstd
           s0[v] += (double)o[v];                             // d bias of the Linear (analytically 0)
         }
-        *reinterpret_cast<float4*>(a.dY + (size_t)m * a.H + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (live) *reinterpret_cast<float4*>(a.dY + (size_t)m * a.H + c0) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
   }
@@ -256,10 +267,13 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
     constexpr int NQ = MODE == CP_BSTAT ? 3 : 1;
     double* dst = a.partial + (size_t)blockIdx.x * NQ * a.H;
     const double* src[3] = {s0, s1, s2};
+#pragma unroll
     for (int qn = 0; qn < NQ; ++qn) {
       __syncthreads();
+      if (live) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) red[slot * a.H + c0 + v] = src[qn][v];
+        for (int v = 0; v < 4; ++v) red[slot * a.H + c0 + v] = src[qn][v];
+      }
       __syncthreads();
       if (tid < a.H) {
         double t = 0.0;
@@ -359,13 +373,12 @@ constexpr int MLP_COL_GRID_MAX = 1024;
 constexpr int MLP_SPLIT_MAX = 64;
 
 bool mlp_train_shape_ok(int rows, int d_in, int hidden, int layers) {
-  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-  return rows > 1 && layers >= 2 && layers <= 8 && pow2(d_in) && d_in >= 16 && d_in <= 256 && pow2(hidden) &&
-         hidden >= 16 && hidden <= 256;
+  return rows > 1 && layers >= 2 && layers <= 8 && d_in % 4 == 0 && d_in >= 4 && d_in <= 256 &&
+         hidden % 4 == 0 && hidden >= 4 && hidden <= 256;
 }
 
 int col_grid(int rows, int H) {
-  const int slots = 256 / (H / 4);
+  const int slots = 256 / col_lanes(H);
   const int want = (rows + slots * 8 - 1) / (slots * 8);
   return max(1, min(MLP_COL_GRID_MAX, min(want, 4 * gdn_cu_count())));
 }

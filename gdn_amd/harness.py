@@ -14,6 +14,8 @@
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -691,8 +693,11 @@ class NativeTrainStep:
     @staticmethod
     def applicable(model) -> bool:
         import torch.nn as nn
-        return (model.out_layer_num == 1 and type(model.dp) is nn.Dropout and model._hip_train_head_ok()
-                and model.injected_graph is None and next(model.parameters()).is_cuda)
+        if not (type(model.dp) is nn.Dropout and model._hip_train_head_ok() and model.injected_graph is None
+                and next(model.parameters()).is_cuda):
+            return False
+        # out_layer_num > 1: the OutLayer MLP must be one gdn_mlp_train_fwd takes (any row count > 1)
+        return model.out_layer_num == 1 or ops.mlp_train_supported(model.out_layer, model.embedding.weight.shape[1], 2)
 
     def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
                  split: bool | None = None, seed: int | None = None):
@@ -749,6 +754,15 @@ class NativeTrainStep:
             d_a=torch.empty((128,), **f32), d_c=torch.empty((2 * n,), **f32),
             mse_ws=ops.mse_workspace(dev),
         )
+        self._mlp = None
+        if model.out_layer_num > 1:
+            hidden, _last = ops.mlp_train_layers(model.out_layer)
+            h, layers = hidden[0][0].out_features, len(hidden) + 1
+            self._mlp = (h, layers, [bn for _lin, bn in hidden])
+            self.ws.update(
+                act=torch.empty((bn_rows, d), **f32), d_act=torch.empty((bn_rows, d), **f32),
+                mlp_saved=torch.empty((lib.gdn_mlp_train_saved_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev),
+                mlp_ws=torch.empty((lib.gdn_mlp_train_workspace_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev))
         self.use_graph = use_graph
         self._graphs = None
         self._split = world()[1] > 1 if split is None else bool(split)
@@ -791,16 +805,39 @@ class NativeTrainStep:
              pt["z"], pt["alpha"], st)
         m1, rm1, rv1, nb1 = self._bn_run(bn1)
         m2, rm2, rv2, nb2 = self._bn_run(bn2)
-        head = (P("gnn_layers.0.bn.weight"), P("gnn_layers.0.bn.bias"), P("bn_outlayer_in.weight"), P("bn_outlayer_in.bias"),
-                P("out_layer.mlp.0.weight"))
-        call("gdn_head_train_fwd_rng", pt["z"], P("embedding.weight"), *head, P("out_layer.mlp.0.bias"), rng, p_drop, b, n, d,
-             float(bn1.eps), float(bn2.eps), m1, m2, rm1, rv1, nb1, rm2, rv2, nb2, pt["stats"], pt["out"], st)
+        bnp = (P("gnn_layers.0.bn.weight"), P("gnn_layers.0.bn.bias"), P("bn_outlayer_in.weight"), P("bn_outlayer_in.bias"))
+        bng = (G("gnn_layers.0.bn.weight"), G("gnn_layers.0.bn.bias"), G("bn_outlayer_in.weight"), G("bn_outlayer_in.bias"))
+        eps = (float(bn1.eps), float(bn2.eps))
+        run = (m1, m2, rm1, rv1, nb1, rm2, rv2, nb2)
+        if self._mlp is None:
+            lw, lb = "out_layer.mlp.0.weight", "out_layer.mlp.0.bias"
+            call("gdn_head_train_fwd_rng", pt["z"], P("embedding.weight"), *bnp, P(lw), P(lb), rng, p_drop, b, n, d,
+                 *eps, *run, pt["stats"], pt["out"], st)
+        else:
+            # out_layer_num > 1: head passes up to the dropped-out activation, then the MLP on the matrix cores
+            h, layers, bns = self._mlp
+            arr = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
+            names = [f"out_layer.mlp.{3 * l + j}.{kind}" for l in range(layers - 1) for j, kind in
+                     ((0, "weight"), (0, "bias"), (1, "weight"), (1, "bias"))]
+            lw, lb = f"out_layer.mlp.{3 * (layers - 1)}.weight", f"out_layer.mlp.{3 * (layers - 1)}.bias"
+            runs = [self._bn_run(bn) for bn in bns]
+            call("gdn_head_train_fwd_act", pt["z"], P("embedding.weight"), *bnp, None, None, 1.0, rng, p_drop, b, n, d,
+                 *eps, *run, pt["stats"], pt["act"], st)
+            call("gdn_mlp_train_fwd", pt["act"], arr([P(nm) for nm in names]),
+                 arr([q for r in runs for q in (r[1], r[2])]), arr([r[3] for r in runs]),
+                 (ctypes.c_float * len(bns))(*[float(bn.eps) for bn in bns]),
+                 (ctypes.c_float * len(bns))(*[r[0] for r in runs]), P(lw), P(lb), b * n, d, h, layers,
+                 pt["mlp_saved"], pt["mlp_ws"], pt["out"], st)
         call("gdn_mse_loss_grad", pt["out"], self.y.data_ptr(), b * n, pt["mse_ws"], self.loss.data_ptr(), pt["d_out"], st)
         # backward: gradients land in their slots of flat_g
-        call("gdn_head_train_bwd_rng", pt["d_out"], pt["z"], P("embedding.weight"), *head, rng, p_drop, pt["stats"], b, n, d,
-             float(bn1.eps), float(bn2.eps), pt["head_ws"], pt["d_z"], G("embedding.weight"), G("gnn_layers.0.bn.weight"),
-             G("gnn_layers.0.bn.bias"), G("bn_outlayer_in.weight"), G("bn_outlayer_in.bias"), G("out_layer.mlp.0.weight"),
-             G("out_layer.mlp.0.bias"), st)
+        if self._mlp is None:
+            call("gdn_head_train_bwd_rng", pt["d_out"], pt["z"], P("embedding.weight"), *bnp, P(lw), rng, p_drop,
+                 pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, G(lw), G(lb), st)
+        else:
+            call("gdn_mlp_train_bwd", pt["d_out"], pt["act"], arr([P(nm) for nm in names]), P(lw), b * n, d, h, layers,
+                 pt["mlp_saved"], pt["mlp_ws"], arr([G(nm) for nm in names]), G(lw), G(lb), pt["d_act"], st)
+            call("gdn_head_train_bwd_act", pt["d_act"], pt["z"], P("embedding.weight"), *bnp, None, None, 1.0, rng,
+                 p_drop, pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, st)
         call("gdn_attn_aggregate_bwd", pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
              pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), st)     # slot cleared by Adam
         call("gdn_project_bwd", self.x.data_ptr(), pt["d_xlin"], pt["d_si"], pt["d_sj"], b, n, w, d, pt["proj_ws"],

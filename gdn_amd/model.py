@@ -117,6 +117,35 @@ class _HeadTrainFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+class _MlpHeadTrainFn(torch.autograd.Function):
+    """out_layer_num > 1 in train mode: the head passes up to the dropped-out activation, then the OutLayer
+    MLP (Linear, batch-statistics BatchNorm, ReLU per hidden layer, Linear(hidden->1)) on the fp32 matrix
+    cores, forward and backward (models/GDN.py:27-56,:77-79,:175-184)."""
+
+    @staticmethod
+    def forward(ctx, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, mask, mask_scale, bn1, bn2, out_layer, batch, *mlp_params):
+        act, stats = ops.head_train_fwd_act(z, emb, bn1, bn2, mask, batch, mask_scale)
+        out, saved = ops.mlp_train_fwd(act, out_layer)
+        hidden, last = ops.mlp_train_layers(out_layer)
+        ctx.save_for_backward(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, stats, act, saved, *mlp_params)
+        ctx.mask, ctx.mask_scale, ctx.eps, ctx.batch = mask, mask_scale, (float(bn1.eps), float(bn2.eps)), batch
+        ctx.geom = (act.shape[1], hidden[0][0].out_features, len(hidden) + 1)
+        ctx.shapes = [p.shape for p in mlp_params]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        z, emb, bn1_w, bn1_b, bn2_w, bn2_b, stats, act, saved, *mlp_params = ctx.saved_tensors
+        d_in, hidden, layers = ctx.geom
+        d_act, grads, d_ow, d_ob = ops.mlp_train_bwd(d_out.contiguous(), act, mlp_params[:-2], mlp_params[-2], saved,
+                                                      d_in, hidden, layers)
+        d_z, d_emb, g1w, g1b, g2w, g2b = ops.head_train_bwd_act(
+            d_act, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, ctx.mask, stats, ctx.eps[0], ctx.eps[1], ctx.batch,
+            ctx.mask_scale)
+        mlp_grads = [g.view(shape) for g, shape in zip(grads + [d_ow, d_ob], ctx.shapes)]
+        return (d_z, d_emb, g1w, g1b, g2w, g2b, None, None, None, None, None, None, *mlp_grads)
+
+
 class GNNLayer(nn.Module):
     """models/GDN.py:60-79.  `att_weight_1` / `edge_index_1` are materialised lazily in the
     reference's edge-list format from the dense per-target attention table."""
@@ -381,7 +410,18 @@ class GDN(nn.Module):
             return _HeadTrainFn.apply(z, emb, layer.bn.weight, layer.bn.bias, self.bn_outlayer_in.weight,
                                       self.bn_outlayer_in.bias, lin.weight, lin.bias, mask, mask_scale, layer.bn,
                                       self.bn_outlayer_in, batch)
-        # out_layer_num > 1 (MLP head): torch for BN statistics, dropout and the library GEMMs
+        if (self.out_layer_num > 1 and self._hip_train_head_ok() and
+                ops.mlp_train_supported(self.out_layer, emb.shape[1], batch * node_num)):
+            hidden, last = ops.mlp_train_layers(self.out_layer)
+            mlp_params = [t for lin, bn in hidden for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
+            mlp_params += [last.weight, last.bias]
+            mask, mask_scale = self._dropout_mask(batch, node_num, emb.shape[1], x.device)
+            out = _MlpHeadTrainFn.apply(z, emb, layer.bn.weight, layer.bn.bias, self.bn_outlayer_in.weight,
+                                        self.bn_outlayer_in.bias, mask, mask_scale, layer.bn, self.bn_outlayer_in,
+                                        self.out_layer, batch, *mlp_params)
+            return out.view(batch, node_num)
+        # MLP head outside gdn_mlp_train_fwd's shapes (hidden not a power of two <= 256): torch for the BN
+        # statistics, dropout and the library GEMMs
         h = layer.relu(layer.bn(z))                                         # GDN.py:77-79
         h = h.view(batch, node_num, -1)                                     # GDN.py:171-172
         h = torch.mul(h, emb)                                               # GDN.py:175-176

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import os
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -245,6 +247,131 @@ def head_train_bwd(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, mask, stats
               batch, n, d, eps1, eps2, _ptr(ws), _ptr(d_z), _ptr(d_emb), _ptr(g1w), _ptr(g1b), _ptr(g2w),
               _ptr(g2b), _ptr(glw), _ptr(glb), _stream())
     return d_z, d_emb, g1w, g1b, g2w, g2b, glw, glb
+
+
+def head_train_fwd_act(z, emb, bn1, bn2, mask, batch: int, mask_scale: float = 1.0):
+    """Train-mode head in front of an OutLayer MLP (out_layer_num > 1): the passes of head_train_fwd ending at
+    the [B*n, d] activation after dropout (models/GDN.py:182) instead of the fused Linear(d->1).
+    Returns (act, stats)."""
+    z = _chk(z, name="z")
+    bn, d = z.shape
+    n = bn // batch
+    act = torch.empty_like(z)
+    stats = torch.empty((_lib.load().gdn_head_train_stats_bytes(d) // 8,), dtype=torch.float64, device=z.device)
+    mptr, kptr, kscale = _mask_args(mask, z.numel(), mask_scale)
+    m1, rm1, rv1, nb1 = _bn_running(bn1)
+    m2, rm2, rv2, nb2 = _bn_running(bn2)
+    _lib.call("gdn_head_train_fwd_act", _ptr(z), _ptr(_chk(emb.detach())), _ptr(_chk(bn1.weight.detach())),
+              _ptr(_chk(bn1.bias.detach())), _ptr(_chk(bn2.weight.detach())), _ptr(_chk(bn2.bias.detach())),
+              mptr, kptr, kscale, None, 0.0, batch, n, d, float(bn1.eps), float(bn2.eps), m1, m2, _ptr(rm1), _ptr(rv1),
+              _ptr(nb1), _ptr(rm2), _ptr(rv2), _ptr(nb2), _ptr(stats), _ptr(act), _stream())
+    return act, stats
+
+
+def head_train_bwd_act(d_act, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, mask, stats, eps1: float, eps2: float,
+                       batch: int, mask_scale: float = 1.0):
+    """Gradients of head_train_fwd_act: (d_z, d_emb, d_bn1_w, d_bn1_b, d_bn2_w, d_bn2_b)."""
+    d_act = _chk(d_act, name="d_act")
+    bn, d = z.shape
+    n = bn // batch
+    dev = z.device
+    ws = torch.empty((_lib.load().gdn_head_train_workspace_bytes(n, d) // 8,), dtype=torch.float64, device=dev)
+    d_z = torch.empty_like(z)
+    d_emb = torch.empty((n, d), dtype=torch.float32, device=dev)
+    small = torch.empty((4 * d,), dtype=torch.float32, device=dev)
+    g1w, g1b, g2w, g2b = (small[i * d:(i + 1) * d] for i in range(4))
+    mptr, kptr, kscale = _mask_args(mask, z.numel(), mask_scale)
+    _lib.call("gdn_head_train_bwd_act", _ptr(d_act), _ptr(z), _ptr(_chk(emb)), _ptr(_chk(bn1_w)), _ptr(_chk(bn1_b)),
+              _ptr(_chk(bn2_w)), _ptr(_chk(bn2_b)), mptr, kptr, kscale, None, 0.0, _ptr(stats), batch, n, d, eps1, eps2,
+              _ptr(ws), _ptr(d_z), _ptr(d_emb), _ptr(g1w), _ptr(g1b), _ptr(g2w), _ptr(g2b), _stream())
+    return d_z, d_emb, g1w, g1b, g2w, g2b
+
+
+def _ptr_array(tensors):
+    """Host array of device pointers (None -> null) for the entry points that take one per layer."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def mlp_train_layers(out_layer):
+    """[(Linear, BatchNorm1d), ...] of the hidden layers and the final Linear of a reference OutLayer
+    (models/GDN.py:27-45), or None when its structure is not that."""
+    mods = list(out_layer.mlp)
+    if len(mods) < 4 or (len(mods) - 1) % 3 != 0:
+        return None
+    hidden = []
+    for i in range(0, len(mods) - 1, 3):
+        lin, bn, act = mods[i], mods[i + 1], mods[i + 2]
+        if not (isinstance(lin, torch.nn.Linear) and isinstance(bn, torch.nn.BatchNorm1d) and
+                isinstance(act, torch.nn.ReLU) and lin.bias is not None and bn.affine):
+            return None
+        if bn.track_running_stats and bn.momentum is None:
+            return None
+        hidden.append((lin, bn))
+    last = mods[-1]
+    if not isinstance(last, torch.nn.Linear) or last.out_features != 1 or last.bias is None:
+        return None
+    return hidden, last
+
+
+def mlp_train_supported(out_layer, d_in: int, rows: int) -> bool:
+    """True when gdn_mlp_train_fwd/bwd take this OutLayer: 2..8 layers, d_in and hidden multiples of 4 up
+    to 256, every hidden layer of the same width."""
+    parts = mlp_train_layers(out_layer)
+    if parts is None:
+        return False
+    hidden, _last = parts
+    h = hidden[0][0].out_features
+    if any(lin.out_features != h for lin, _ in hidden) or hidden[0][0].in_features != d_in:
+        return False
+    return _lib.load().gdn_mlp_train_saved_bytes(rows, d_in, h, len(hidden) + 1) > 0
+
+
+def mlp_train_fwd(act, out_layer):
+    """Train-mode OutLayer MLP forward (models/GDN.py:47-56 under model.train(): Linear, batch-statistics
+    BatchNorm, ReLU per hidden layer, then Linear(hidden->1)).  Returns (out[rows], saved); updates the
+    BatchNorm running statistics in place."""
+    act = _chk(act, name="act")
+    rows, d_in = act.shape
+    hidden, last = mlp_train_layers(out_layer)
+    h, layers = hidden[0][0].out_features, len(hidden) + 1
+    lib = _lib.load()
+    saved = torch.empty((lib.gdn_mlp_train_saved_bytes(rows, d_in, h, layers),), dtype=torch.uint8, device=act.device)
+    ws = torch.empty((lib.gdn_mlp_train_workspace_bytes(rows, d_in, h, layers),), dtype=torch.uint8, device=act.device)
+    out = torch.empty((rows,), dtype=torch.float32, device=act.device)
+    params, running, batches, eps, mom = [], [], [], [], []
+    for lin, bn in hidden:
+        params += [_chk(lin.weight.detach()), _chk(lin.bias.detach()), _chk(bn.weight.detach()), _chk(bn.bias.detach())]
+        m, rm, rv, nb = _bn_running(bn)
+        running += [rm, rv]
+        batches.append(nb)
+        eps.append(float(bn.eps))
+        mom.append(m)
+    _lib.call("gdn_mlp_train_fwd", _ptr(act), _ptr_array(params), _ptr_array(running), _ptr_array(batches),
+              (ctypes.c_float * len(eps))(*eps), (ctypes.c_float * len(mom))(*mom),
+              _ptr(_chk(last.weight.detach().reshape(-1))), _ptr(_chk(last.bias.detach().reshape(-1))),
+              rows, d_in, h, layers, _ptr(saved), _ptr(ws), _ptr(out), _stream())
+    return out, saved
+
+
+def mlp_train_bwd(d_out, act, params, out_w, saved, d_in: int, hidden: int, layers: int):
+    """Gradients of mlp_train_fwd.  `params` = [W, b, gamma, beta] * (layers-1).  Returns
+    (d_act, [dW, db, dgamma, dbeta] * (layers-1), d_out_w[hidden], d_out_b[1])."""
+    d_out = _chk(d_out.reshape(-1), name="d_out")
+    rows = act.shape[0]
+    dev = act.device
+    ws = torch.empty((_lib.load().gdn_mlp_train_workspace_bytes(rows, d_in, hidden, layers),), dtype=torch.uint8, device=dev)
+    grads = []
+    for l in range(layers - 1):
+        k = d_in if l == 0 else hidden
+        grads += [torch.empty((hidden, k), dtype=torch.float32, device=dev)] + \
+                 [torch.empty((hidden,), dtype=torch.float32, device=dev) for _ in range(3)]
+    d_ow = torch.empty((hidden,), dtype=torch.float32, device=dev)
+    d_ob = torch.empty((1,), dtype=torch.float32, device=dev)
+    d_act = torch.empty_like(act)
+    _lib.call("gdn_mlp_train_bwd", _ptr(d_out), _ptr(act), _ptr_array([_chk(p) for p in params]),
+              _ptr(_chk(out_w.reshape(-1))), rows, d_in, hidden, layers, _ptr(saved), _ptr(ws), _ptr_array(grads),
+              _ptr(d_ow), _ptr(d_ob), _ptr(d_act), _stream())
+    return d_act, grads, d_ow, d_ob
 
 
 def forward_fused(x, lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,

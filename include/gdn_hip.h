@@ -45,7 +45,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 13
+#define GDN_ABI_VERSION 14
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -186,6 +186,47 @@ int gdn_head_train_bwd_rng(const float* d_out, const float* z, const float* emb,
                            const double* stats, int batch, int n, int d, float eps1, float eps2,
                            double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
                            float* d_bn2_w, float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);
+
+/* ---- train-mode OutLayer MLP, out_layer_num > 1 (models/GDN.py:27-56 under model.train()) ----------
+ * The head passes above end at the [B*n, d] activation after dropout (forward: `act`) / start from its
+ * gradient (backward: `d_act`) instead of the fused Linear(d -> 1); mask / keep as in gdn_head_train_fwd,
+ * or (both null, rng_seed_step given, p_drop > 0) the in-kernel draw of the _rng entry points.          */
+int gdn_head_train_fwd_act(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                           const float* bn2_w, const float* bn2_b, const float* mask,
+                           const uint8_t* keep, float keep_scale, const long long* rng_seed_step,
+                           float p_drop, int batch, int n, int d, float eps1,
+                           float eps2, float momentum1, float momentum2, float* running_mean1,
+                           float* running_var1, long long* batches1, float* running_mean2,
+                           float* running_var2, long long* batches2, double* stats, float* act,
+                           void* stream);
+int gdn_head_train_bwd_act(const float* d_act, const float* z, const float* emb, const float* bn1_w,
+                           const float* bn1_b, const float* bn2_w, const float* bn2_b,
+                           const float* mask, const uint8_t* keep, float keep_scale,
+                           const long long* rng_seed_step, float p_drop,
+                           const double* stats, int batch, int n, int d, float eps1, float eps2,
+                           double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
+                           float* d_bn2_w, float* d_bn2_b, void* stream);
+/* The MLP itself: Y_l = A_l W_l^T + b_l, A_{l+1} = relu(BatchNorm_train(Y_l)) for l = 0..layers-2 (A_0 = act
+ * [rows, d_in]), out = A_{layers-1} w_o + b_o — replaces OutLayer.forward (models/GDN.py:47-56) and the
+ * autograd graph behind train.py:72.  fp32 matrix cores (exact fp32 products), batch statistics and every
+ * reduction in fp64 in a fixed order (bitwise reproducible).  params[4*l .. 4*l+3] = {W_l [hidden, K_l],
+ * b_l, gamma_l, beta_l} (K_0 = d_in, K_l = hidden), running[2*l .. 2*l+1] = {running_mean, running_var} (null
+ * = not tracked), batches[l] = num_batches_tracked or null; eps[l], momentum[l]: host floats.  The arrays
+ * of pointers live in HOST memory and hold device pointers.  `saved` (gdn_mlp_train_saved_bytes) carries the
+ * pre-BatchNorm outputs and the batch constants from the forward to the backward; `workspace`
+ * (gdn_mlp_train_workspace_bytes) is scratch.  grads[4*l .. 4*l+3] = gradients in the layout of params.
+ * Supported: layers 2..8, d_in and hidden multiples of 4 up to 256 (else GDN_ERR_UNSUPPORTED; the byte
+ * counts are 0 then).                                                                                     */
+long long gdn_mlp_train_saved_bytes(int rows, int d_in, int hidden, int layers);
+long long gdn_mlp_train_workspace_bytes(int rows, int d_in, int hidden, int layers);
+int gdn_mlp_train_fwd(const float* act, const float* const* params, float* const* running,
+                      long long* const* batches, const float* eps, const float* momentum,
+                      const float* out_w, const float* out_b, int rows, int d_in, int hidden,
+                      int layers, void* saved, void* workspace, float* out, void* stream);
+int gdn_mlp_train_bwd(const float* d_out, const float* act, const float* const* params,
+                      const float* out_w, int rows, int d_in, int hidden, int layers,
+                      const void* saved, void* workspace, float* const* grads, float* d_out_w,
+                      float* d_out_b, float* d_act, void* stream);
 
 /* gdn_adam_step: torch.optim.Adam(lr, betas, eps, weight_decay) of train.py:31,73 over ONE flat fp32
  * buffer holding every parameter back to back (params / grads / exp_avg / exp_avg_sq: [count]); step[0] =

@@ -96,10 +96,11 @@ def test_end_to_end_forward_learns_its_own_graph(case, gpu_device):
         np.testing.assert_allclose(layer.att_weight_1.cpu().numpy(), data["att_weight_1"], atol=TOL, rtol=0)
 
 
-def random_params(n, w, k, d, seed):
+def random_params(n, w, k, d, seed, out_layer_num=1, inter=256):
     from gdn_amd import GDN
     torch.manual_seed(seed)
-    model = GDN([torch.zeros((2, 1), dtype=torch.long)], n, dim=d, input_dim=w, topk=k)
+    model = GDN([torch.zeros((2, 1), dtype=torch.long)], n, dim=d, input_dim=w, topk=k, out_layer_num=out_layer_num,
+                out_layer_inter_dim=inter)
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         gnn = model.gnn_layers[0].gnn

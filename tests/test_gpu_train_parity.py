@@ -491,8 +491,8 @@ def _mix32_mask(seed, step, count, p_drop, device):
     return x >= int(p_drop * 4294967296.0)
 
 
-@pytest.mark.parametrize("p_drop", [0.0, 0.2])
-def test_native_train_step_equals_the_autograd_step(p_drop, gpu_device):
+@pytest.mark.parametrize("p_drop,layers", [(0.0, 1), (0.2, 1), (0.2, 2), (0.0, 3)])
+def test_native_train_step_equals_the_autograd_step(p_drop, layers, gpu_device):
     """NativeTrainStep (no autograd, gradients straight into the flat bucket, gdn_adam_step, dropout drawn in the
     kernels) against the autograd + torch.optim.Adam path fed THE SAME dropout masks (recomputed here from the
     documented hash): per-step losses, gradients of the first step, parameters after 5 steps."""
@@ -503,13 +503,14 @@ def test_native_train_step_equals_the_autograd_step(p_drop, gpu_device):
     xs = torch.rand((steps, b, n, w), generator=g).to(gpu_device)
     ys = torch.rand((steps, b, n), generator=g).to(gpu_device)
 
-    model = random_params(n, w, k, d, seed=9).to(gpu_device)
+    model = random_params(n, w, k, d, seed=9, out_layer_num=layers, inter=128).to(gpu_device)
     model.dp.p = p_drop
+    assert harness.NativeTrainStep.applicable(model)
     nat = harness.NativeTrainStep(model, b, use_graph=True, seed=seed)
     assert all(p.data_ptr() >= nat.flat_p.data_ptr() and p.data_ptr() < nat.flat_p.data_ptr() + 4 * nat.count
                for p in model.parameters())          # the parameters ARE views of the flat buffer
 
-    ref = random_params(n, w, k, d, seed=9).to(gpu_device).train()
+    ref = random_params(n, w, k, d, seed=9, out_layer_num=layers, inter=128).to(gpu_device).train()
     masks = [(_mix32_mask(seed, t, b * n * d, p_drop, gpu_device).float() / (1.0 - p_drop)).view(b, n, d)
              for t in range(steps)]
     ref.dp = FixedMaskDropout(masks)
@@ -531,7 +532,11 @@ def test_native_train_step_equals_the_autograd_step(p_drop, gpu_device):
         assert abs(loss_n - float(loss_r.detach())) < 2e-6, (t, loss_n, float(loss_r.detach()))
     assert int(nat.state[1]) == steps
     for name, pa, pb in zip(names, model.parameters(), ref.parameters()):
-        tol = 6e-3 if name.endswith("gnn.bias") else 2e-5
+        # parameters whose true gradient is 0 (a bias in front of a train-mode BatchNorm: gnn.bias and the hidden
+        # Linear biases of the MLP) see pure rounding noise, and Adam turns noise of either sign into +-lr steps
+        noise_only = name.endswith("gnn.bias") or (name.startswith("out_layer.mlp.") and name.endswith(".bias")
+                                                   and name != f"out_layer.mlp.{3 * (layers - 1)}.bias")
+        tol = 6e-3 if noise_only else 2e-5
         np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), atol=tol, err_msg=name)
     if p_drop > 0:
         kept = torch.stack(masks).ne(0).float().mean().item()
@@ -588,3 +593,77 @@ def test_training_step_at_the_512_sensor_stress_shape(gpu_device):
     for name, prm in model.named_parameters():
         np.testing.assert_allclose(prm.grad.cpu().numpy().astype(np.float64), leaf[name].grad.numpy(), atol=2e-6,
                                    rtol=1e-5, err_msg=name)
+
+
+# ---------------------------------------------------------------- train-mode OutLayer MLP (out_layer_num > 1)
+@pytest.mark.parametrize("rows,d_in,hidden,layers", [(60, 32, 48, 2), (60, 16, 24, 3), (4064, 64, 256, 2),
+                                                     (3456, 64, 128, 3), (1000, 128, 64, 4), (131, 64, 256, 2)])
+def test_mlp_train_kernels_match_fp64_autograd(rows, d_in, hidden, layers, gpu_device):
+    """gdn_mlp_train_fwd / gdn_mlp_train_bwd (fp32 matrix cores, fp64 statistics) against the reference's
+    OutLayer (models/GDN.py:27-56) run by torch autograd in float64: output, every parameter gradient, the
+    input gradient, the BatchNorm running statistics."""
+    from gdn_amd import ops
+    from gdn_amd.model import OutLayer
+    torch.manual_seed(rows + hidden)
+    ref = OutLayer(d_in, 1, layers, inter_num=hidden).double()
+    with torch.no_grad():
+        for mod in ref.mlp:
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.3, 0.3)
+    hip = OutLayer(d_in, 1, layers, inter_num=hidden)
+    hip.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    hip = hip.to(gpu_device).train()
+    ref.train()
+    act = torch.rand((rows, d_in), dtype=torch.float64) * (torch.rand((rows, d_in)) > 0.2)   # post-ReLU/dropout-like
+    d_out = torch.randn((rows,), dtype=torch.float64) / rows
+    a64 = act.clone().requires_grad_(True)
+    out64 = ref(a64.view(1, rows, d_in)).view(rows)              # BatchNorm over the rows, as GDN.py:53-54
+    out64.backward(d_out)
+    assert ops.mlp_train_supported(hip, d_in, rows)
+    act_d = act.float().to(gpu_device)
+    out, saved = ops.mlp_train_fwd(act_d, hip)
+    np.testing.assert_allclose(out.cpu().double().numpy(), out64.detach().numpy(), atol=5e-6, rtol=1e-5)
+    hidden_mods, last = ops.mlp_train_layers(hip)
+    params = [t.detach() for lin, bn in hidden_mods for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
+    d_act, grads, d_ow, d_ob = ops.mlp_train_bwd(d_out.float().to(gpu_device), act_d, params, last.weight.detach(),
+                                                 saved, d_in, hidden, layers)
+    ref_hidden, ref_last = ops.mlp_train_layers(ref)
+    want = [t.grad for lin, bn in ref_hidden for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
+    scale = max(float(w.abs().max()) for w in want)
+    for i, (g, w) in enumerate(zip(grads, want)):
+        np.testing.assert_allclose(g.cpu().double().numpy(), w.numpy(), atol=2e-6 * max(scale, 1.0), rtol=2e-5,
+                                   err_msg=f"hidden-layer gradient {i}")
+    np.testing.assert_allclose(d_ow.cpu().double().numpy(), ref_last.weight.grad.view(-1).numpy(), atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(d_ob.cpu().double().numpy(), ref_last.bias.grad.numpy(), atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(d_act.cpu().double().numpy(), a64.grad.numpy(), atol=2e-7, rtol=2e-5)
+    for (lin, bn), (_rl, rbn) in zip(hidden_mods, ref_hidden):
+        np.testing.assert_allclose(bn.running_mean.cpu().double().numpy(), rbn.running_mean.numpy(), atol=1e-6)
+        np.testing.assert_allclose(bn.running_var.cpu().double().numpy(), rbn.running_var.numpy(), atol=1e-6, rtol=1e-5)
+        assert int(bn.num_batches_tracked) == 1
+    # bitwise reproducible: fixed-order reductions, no atomics
+    out2, saved2 = ops.mlp_train_fwd(act_d, hip)
+    d_act2, grads2, _, _ = ops.mlp_train_bwd(d_out.float().to(gpu_device), act_d, params, last.weight.detach(), saved2,
+                                             d_in, hidden, layers)
+    assert torch.equal(out, out2) and torch.equal(d_act, d_act2)
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads2))
+
+
+def test_mlp_head_training_uses_the_hip_mlp(gpu_device, monkeypatch):
+    """out_layer_num = 2 under model.train(): forward + backward go through _MlpHeadTrainFn (HIP head passes
+    + HIP MLP); a hidden width outside the HIP set (not a multiple of 4) falls back to torch instead of failing."""
+    import gdn_amd
+    from gdn_amd import ops
+    calls = []
+    orig = ops.mlp_train_fwd
+    monkeypatch.setattr(ops, "mlp_train_fwd", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    for hidden, expect in ((256, 1), (250, 0)):
+        torch.manual_seed(0)
+        model = gdn_amd.GDN([torch.zeros((2, 1), dtype=torch.long)], 27, dim=64, input_dim=15, out_layer_num=2,
+                            out_layer_inter_dim=hidden, topk=10).to(gpu_device).train()
+        x = torch.rand((8, 27, 15), device=gpu_device)
+        calls.clear()
+        loss = model(x, None).square().mean()
+        loss.backward()
+        assert len(calls) == expect
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
