@@ -332,28 +332,59 @@ constexpr int ONE_FK = 32;
 constexpr int ONE_CAP = 8192;   // 16-bit-prefix survivors kept in LDS (64 KB)
 constexpr int ONE_CAP2 = 1024;  // 24-bit-prefix survivors finished by counting
 
+template <bool FLAT>
 __global__ __launch_bounds__(ONE_NT) void select_onewg_kernel(const KeyLayout kl, const SelectArgs sa,
                                                               double* __restrict__ med_iqr) {
   __shared__ unsigned int hist[NQ][256];
   __shared__ unsigned long long prefix[NQ];
   __shared__ unsigned long long stage[ONE_CAP];
   __shared__ unsigned long long stage2[ONE_CAP2];
+  __shared__ unsigned short sidx[ONE_CAP];   // slot numbers of the 16-bit-prefix survivors
   __shared__ int rem[NQ];
   __shared__ int rep[NQ];
-  __shared__ unsigned int n_stage, n_stage2;
+  __shared__ unsigned int n_stage, n_stage2, dref;
+  __shared__ unsigned int cnt0[2];
   const int s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const unsigned int slots = (unsigned int)kl.blocks * (unsigned int)kl.pitch;
-  unsigned long long key[ONE_FK];
+#ifdef GDN_SELECT_TIMING
+  const long long tick_start = wall_clock64();
+#endif
+  // Only the HIGH words stay in registers (digits 0-2 and both compactions look at nothing else): 32 VGPRs
+  // instead of 64 — with the full keys the kernel spilled 47 VGPRs + 172 SGPRs at its 128-register budget
+  // (4 waves per SIMD) and every pass paid scratch traffic.  The few keys that survive the 16-bit compaction
+  // are re-read in full (L2-resident: the sensor's row was just streamed).
+  constexpr bool flat = FLAT;                              // blocks == 1 (single GPU): the sensor's row is contiguous
+  // flat rows go through a buffer descriptor: per-thread offset in ONE register, the slot offset u*8 KB a
+  // scalar (64-bit pointers per slot cost 64 VGPRs and spilled); reads past the row return 0
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned long long*>(kl.keys + (size_t)s * kl.pitch), 0, flat ? kl.pitch * 8 : 0, 0x00020000);
+  auto key_full = [&](int u) -> unsigned long long {
+    if constexpr (flat) {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, tid * 8, u * (ONE_NT * 8), 0);
+      return ((unsigned long long)v.y << 32) | v.x;
+    } else {
+      const unsigned int i = tid + u * ONE_NT;
+      const unsigned int blk = i / (unsigned int)kl.pitch, off = i - blk * (unsigned int)kl.pitch;
+      return kl.keys[((size_t)blk * kl.n + s) * kl.pitch + off];
+    }
+  };
+  auto key_slot = [&](unsigned int i) -> unsigned long long {     // slot number -> full key
+    if constexpr (flat) {
+      return kl.keys[(size_t)s * kl.pitch + i];
+    } else {
+      const unsigned int blk = i / (unsigned int)kl.pitch, off = i - blk * (unsigned int)kl.pitch;
+      return kl.keys[((size_t)blk * kl.n + s) * kl.pitch + off];
+    }
+  };
+  unsigned int khi[ONE_FK];
 #pragma unroll
   for (int u = 0; u < ONE_FK; ++u) {
-    const unsigned int i = tid + u * ONE_NT;
-    unsigned long long k = FILLER;
-    if (i < slots) {
-      const unsigned int blk = i / (unsigned int)kl.pitch, off = i - blk * (unsigned int)kl.pitch;
-      k = kl.keys[((size_t)blk * kl.n + s) * kl.pitch + off];
-    }
-    key[u] = k;
+    unsigned int hi;
+    if constexpr (flat) hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, tid * 8 + 4, u * (ONE_NT * 8), 0);
+    else hi = tid + u * ONE_NT < slots ? (unsigned int)(key_full(u) >> 32) : 0u;
+    khi[u] = tid + u * ONE_NT < slots ? hi : 0xffffffffu;   // filler: never a real key
   }
   if (tid < NQ) {
     prefix[tid] = 0ull;
@@ -381,63 +412,109 @@ __global__ __launch_bounds__(ONE_NT) void select_onewg_kernel(const KeyLayout kl
       rep[tid] = r;
     }
     for (int i = tid; i < NQ * 256; i += ONE_NT) (&hist[0][0])[i] = 0u;
-    __syncthreads();
-    unsigned long long pf[NQ];
-    bool active[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      pf[q] = prefix[q];
-      active[q] = rep[q] == q;
+    if (pass == 0 && tid == 0) {
+      cnt0[0] = cnt0[1] = 0u;
+      dref = khi[0] >> 24;                 // top byte of tick 0's key: the bin of (nearly) every key
     }
+    __syncthreads();
+    if (pass == 0) {
+      // Digit 0 without a histogram: errors of one sensor almost always share the top byte (sign + 7
+      // exponent bits), so COUNT the keys below / inside the reference bin (compares and adds in registers,
+      // one LDS atomic pair per wave); if every rank falls inside it the digit is known.  Otherwise (ranks in
+      // several bins) the generic histogram below runs.
+      const unsigned int dr = dref;
+      unsigned int less = 0u, same = 0u;
+#pragma unroll
+      for (int u = 0; u < ONE_FK; ++u) {
+        const unsigned int hi = khi[u];
+        const unsigned int digit = hi >> 24;             // the filler's digit is 255: never less, never same
+        less += digit < dr ? 1u : 0u;
+        same += digit == dr ? 1u : 0u;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        less += __shfl_xor(less, d);
+        same += __shfl_xor(same, d);
+      }
+      if (lane == 0) {
+        atomicAdd(&cnt0[0], less);
+        atomicAdd(&cnt0[1], same);
+      }
+      __syncthreads();
+      const unsigned int tl = cnt0[0], ts = cnt0[1];
+      bool inside = dr != 255u;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) inside = inside && (unsigned int)sa.rank[q] >= tl && (unsigned int)sa.rank[q] < tl + ts;
+      if (inside) {                                        // uniform
+        if (tid < NQ) {
+          prefix[tid] = (unsigned long long)dr << 56;
+          rem[tid] = sa.rank[tid] - (int)tl;
+        }
+        __syncthreads();
+#ifdef GDN_SELECT_TIMING
+        tick[nt++] = wall_clock64();
+#endif
+        continue;
+      }
+    }
+    // One REAL loop over the ranks (not unrolled: with the 32 key slots unrolled inside six copies of every
+    // branch the kernel was 34 k instructions and spilled ~110 SGPRs); ranks that share their prefix with an
+    // earlier one are skipped (uniform).
     if (!in_lds && pass < 3) {
       // digits 0-2 live in the HIGH word of the key: 32-bit shifts and compares
       const unsigned int sh = 24u - 8u * (unsigned int)pass;
-      unsigned int pfh[NQ];
+#pragma nounroll
+      for (int q = 0; q < NQ; ++q) {
+        if (rep[q] != q) continue;
+        const unsigned int pfh = (unsigned int)(prefix[q] >> 32);
+        unsigned int* hq = hist[q];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) pfh[q] = (unsigned int)(pf[q] >> 32);
-#pragma unroll
-      for (int u = 0; u < ONE_FK; ++u) {
-        const unsigned int hi = (unsigned int)(key[u] >> 32);
-        const bool real = (int)hi >= 0;               // keys are non-negative doubles; the filler is all ones
-        const unsigned int digit = (hi >> sh) & 255u;
-        const unsigned int d0 = __builtin_amdgcn_readfirstlane(digit);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          if (!active[q]) continue;   // uniform
-          const bool match = real && (pass == 0 ? true : ((hi ^ pfh[q]) >> (sh + 8u)) == 0u);
-          if (__all(match && digit == d0)) {          // a whole wave in one bin (the exponent bytes): one add
-            if (lane == 0) atomicAdd(&hist[q][d0], 64u);
-          } else if (match) {
-            atomicAdd(&hist[q][digit], 1u);
+        for (int u = 0; u < ONE_FK; ++u) {
+          const unsigned int hi = khi[u];
+          const bool real = (int)hi >= 0;               // keys are non-negative doubles; the filler is all ones
+          const unsigned int digit = (hi >> sh) & 255u;
+          if (pass == 0) {                              // (only when the counting path above gave up)
+            const unsigned int d0 = __builtin_amdgcn_readfirstlane(digit);
+            if (__all(real && digit == d0)) {           // a whole wave in one bin: one add
+              if (lane == 0) atomicAdd(&hq[d0], 64u);
+            } else if (real) {
+              atomicAdd(&hq[digit], 1u);
+            }
+          } else if (real && ((hi ^ pfh) >> (sh + 8u)) == 0u) {
+            atomicAdd(&hq[digit], 1u);
           }
         }
       }
     } else if (!in_lds) {
-#pragma unroll
-      for (int u = 0; u < ONE_FK; ++u) {
-        const unsigned long long k = key[u];
-        const bool real = k != FILLER;
-        const unsigned int digit = (unsigned int)(k >> shift) & 255u;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          if (!active[q]) continue;
-          if (real && ((k ^ pf[q]) >> (shift + 8)) == 0ull) atomicAdd(&hist[q][digit], 1u);
+#pragma nounroll
+      for (int q = 0; q < NQ; ++q) {
+        if (rep[q] != q) continue;
+        const unsigned long long pfq = prefix[q];
+        unsigned int* hq = hist[q];
+#pragma unroll 4
+        for (int u = 0; u < ONE_FK; ++u) {      // compaction defeated (rare): full keys re-read per digit
+          const bool real = (int)khi[u] >= 0;
+          const unsigned long long k = real ? key_full(u) : FILLER;
+          const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+          if (real && ((k ^ pfq) >> (shift + 8)) == 0ull) atomicAdd(&hq[digit], 1u);
         }
       }
     } else {
-      for (unsigned int i = tid; i < n_keep; i += ONE_NT) {
-        const unsigned long long k = stage[i];
-        const unsigned int digit = (unsigned int)(k >> shift) & 255u;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          if (!active[q]) continue;
-          if (((k ^ pf[q]) >> (shift + 8)) == 0ull) atomicAdd(&hist[q][digit], 1u);
+#pragma nounroll
+      for (int q = 0; q < NQ; ++q) {
+        if (rep[q] != q) continue;
+        const unsigned long long pfq = prefix[q];
+        unsigned int* hq = hist[q];
+        for (unsigned int i = tid; i < n_keep; i += ONE_NT) {
+          const unsigned long long k = stage[i];
+          const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+          if (((k ^ pfq) >> (shift + 8)) == 0ull) atomicAdd(&hq[digit], 1u);
         }
       }
     }
     __syncthreads();
     for (int q = wv; q < NQ; q += ONE_NT / 64)
-      locate_bin(hist[rep[q]], rem[q], pf[q], shift, lane, &prefix[q], &rem[q]);
+      locate_bin(hist[rep[q]], rem[q], prefix[q], shift, lane, &prefix[q], &rem[q]);
     __syncthreads();
     if (pass == 1) {
       // compact the keys that still match some rank's 16-bit prefix; stay in registers if they do not fit
@@ -452,7 +529,7 @@ __global__ __launch_bounds__(ONE_NT) void select_onewg_kernel(const KeyLayout kl
       unsigned int keep = 0u;                          // bit u: my key u survives
 #pragma unroll
       for (int u = 0; u < ONE_FK; ++u) {
-        const unsigned int h16 = (unsigned int)(key[u] >> 48);   // the filler (0xffff) never equals a prefix
+        const unsigned int h16 = khi[u] >> 16;   // the filler (0xffff) never equals a prefix
         bool any = false;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) any |= h16 == p16[q];
@@ -470,16 +547,24 @@ __global__ __launch_bounds__(ONE_NT) void select_onewg_kernel(const KeyLayout kl
       if (lane == 63) base = atomicAdd(&n_stage, (unsigned int)incl);
       base = __shfl(base, 63);
       unsigned int pos = base + (unsigned int)(incl - mine);
+      // survivors first as SLOT NUMBERS, then re-read in full by all threads at once (a load inside the
+      // per-slot branch would pay one L2 round trip per survivor, serially)
+      unsigned int t1 = tid;
+      asm volatile("" : "+v"(t1));     // keeps the 32 slot numbers from being precomputed outside the pass loop
 #pragma unroll
       for (int u = 0; u < ONE_FK; ++u) {
         if ((keep >> u) & 1u) {
-          if (pos < (unsigned int)ONE_CAP) stage[pos] = key[u];
+          if (pos < (unsigned int)ONE_CAP) sidx[pos] = (unsigned short)(t1 + u * ONE_NT);   // slots <= 32768
           ++pos;
         }
       }
       __syncthreads();
       n_keep = n_stage;
       in_lds = n_keep <= (unsigned int)ONE_CAP;
+      if (in_lds) {
+        for (unsigned int i = tid; i < n_keep; i += ONE_NT) stage[i] = key_slot(sidx[i]);
+        __syncthreads();
+      }
     }
     if (pass == 2 && in_lds) {
       // second compaction (24-bit prefixes), then finish every rank by counting inside its bucket
@@ -523,8 +608,8 @@ __global__ __launch_bounds__(ONE_NT) void select_onewg_kernel(const KeyLayout kl
   }
 #ifdef GDN_SELECT_TIMING
   if (tid == 0 && s == 1)
-    printf("onewg ticks(10ns): load+p0 %lld p1+compact %lld p2+finish %lld (passes run %d) survivors %u / %u\n",
-           tick[1] - tick[0], tick[2] - tick[1], tick[3] - tick[2], nt - 1, n_keep, n_stage2);
+    printf("onewg ticks(10ns): load %lld p0 %lld p1+compact %lld p2+finish %lld (passes run %d) survivors %u / %u\n",
+           tick[0] - tick_start, tick[1] - tick[0], tick[2] - tick[1], tick[3] - tick[2], nt - 1, n_keep, n_stage2);
 #endif
   if (tid == 0) write_result(prefix, sa, s, med_iqr);
 }
@@ -640,7 +725,8 @@ int run_select(const double* keys, int blocks, int n, int pitch, long long total
   const int slices = (int)((slots + SLICE - 1) / SLICE);
   if (slices > 1 && slots <= (long long)ONE_NT * ONE_FK && !force_multi_block()) {
     // the whole sensor fits one workgroup's registers: one launch, no global state
-    hipLaunchKernelGGL(select_onewg_kernel, dim3(n), dim3(ONE_NT), 0, st, kl, sa, med_iqr);
+    if (kl.blocks == 1) hipLaunchKernelGGL(select_onewg_kernel<true>, dim3(n), dim3(ONE_NT), 0, st, kl, sa, med_iqr);
+    else hipLaunchKernelGGL(select_onewg_kernel<false>, dim3(n), dim3(ONE_NT), 0, st, kl, sa, med_iqr);
     return gdn_launch_status();
   }
   hipLaunchKernelGGL(select_init_kernel, dim3(n), dim3(256), 0, st, state, sa);
