@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: sliding-windows/sec, eval forward + anomaly score, SWaT-shape
 (BASELINE.json metric; workload = configs[2]: 127 sensors, top-k 30, W=15, D=64, batch 512).
-The series is resident, so by default 8 consecutive 512-window minibatches go out as one launch
-(`--coalesce 1` launches per minibatch; `value_per_batch_launches` reports that variant too).
+The series is resident, so by default all 64 consecutive 512-window minibatches of a step go out as ONE launch
+(`--coalesce 8 --streams 2` was round 1's form: 5 % slower — every workgroup pays its prologue per launch;
+`--coalesce 1` launches per minibatch; `value_per_batch_launches` reports that variant too).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -250,12 +251,12 @@ def run():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=512, help="logical minibatch (BASELINE configs[2])")
-    ap.add_argument("--coalesce", type=int, default=8,
+    ap.add_argument("--coalesce", type=int, default=64,
                     help="consecutive minibatches of the resident series sent as one launch (1 = per-batch launches)")
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="side streams the forward launches rotate over")
+    ap.add_argument("--streams", type=int, default=1, help="side streams the forward launches rotate over")
     ap.add_argument("--exchange-chunk", type=int, default=32768,
                     help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
     ap.add_argument("--sweep-max", type=int, default=262144,
@@ -309,15 +310,18 @@ def run():
     # roofline numbers this leaves the GPU at steady clocks when the W warm-up steps begin — it needs ~50 ms
     # of load after an idle period to get there (tools/probe_ramp.py), and W steps alone are a few ms.
     launches_for = lambda b: max(12, min(64, 65536 // b))
-    sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sorted({batch, launch_batch, t})]
+    sizes = sorted({batch, min(4096, t), launch_batch, t})      # 4096: the launch size rounds 1-2 quoted
+    sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sizes]
     if world == 1 and args.sweep_max > t:       # the fraction at the largest per-GPU launch
         xbig = torch.rand((args.sweep_max, N_SENSORS, WINDOW), device=device)     # 2 GB; xlin + z: 17 GB
         sweep.append(k8_roofline(model, xbig, args.sweep_max, launches=12))
         del xbig
         torch.cuda.empty_cache()
     fused_leg = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch))
+    fused_sweep = [fused_leg if b == launch_batch else fused_roofline(model, x, ev.pred, b, launches=launches_for(b))
+                   for b in sizes]
     # BASELINE configs[2] says bf16: the same kernels with x / xlin / z stored in bf16 (fp32 arithmetic)
-    sweep_bf16 = [k8_roofline(model, x, b, launches=launches_for(b), storage="bf16") for b in sorted({batch, launch_batch, t})]
+    sweep_bf16 = [k8_roofline(model, x, b, launches=launches_for(b), storage="bf16") for b in sizes]
     fused_leg_bf16 = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch), storage="bf16")
 
     def timed(fn, steps):
@@ -384,6 +388,8 @@ def run():
         result["roofline_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
                                      "launch_us": r["launch_us"]} for r in sweep]
         result["roofline_fused"] = fused_leg
+        result["roofline_fused_sweep"] = [{"batch": r["batch"], "launch_us": r["launch_us"], "windows_per_s": r["windows_per_s"]}
+                                          for r in fused_sweep]
         result["roofline_bf16"] = next(r for r in sweep_bf16 if r["batch"] == launch_batch)
         result["roofline_bf16_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
                                           "launch_us": r["launch_us"]} for r in sweep_bf16]

@@ -270,3 +270,35 @@ def test_threshold_sweep_full_size_against_oracle(gpu_device):
     for topk in (1, 2):
         got = evaluate.get_best_performance_data(scores, labels, topk=topk, device=gpu_device)
         np.testing.assert_allclose(got, score_oracle.best_performance(scores, labels, topk), rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("t", [32768, 20000, 5000, 40000])
+def test_quantile_select_on_adversarial_error_distributions(t, gpu_device):
+    """Every sensor's median / IQR must equal numpy's bit for bit whatever the shape of the error distribution:
+    the one-workgroup select (t <= 32768) decides digit 0 by COUNTING around the top byte of tick 0's key and
+    falls back to histograms when the ranks leave that bin, compacts by 16- and 24-bit prefixes and falls back
+    when the compaction does not fit; the multi-launch select (t > 32768) has its own hand-offs."""
+    from gdn_amd import evaluate
+    g = torch.Generator().manual_seed(t)
+    n = 12
+    pred = torch.zeros((t, n))
+    err = torch.empty((t, n), dtype=torch.float64)
+    err[:, 0] = torch.exp(12.0 * torch.randn((t,), generator=g, dtype=torch.float64)).clamp(1e-30, 1e30)   # ~100 binades: ranks in different top bytes
+    err[:, 1] = torch.rand((t,), generator=g, dtype=torch.float64) * 1e-3
+    err[0, 1] = 5e4                                                                       # tick 0 is an outlier: wrong reference bin
+    err[:, 2] = 0.25                                                                      # constant: every key equal
+    err[:, 3] = torch.randint(0, 3, (t,), generator=g).double() * 0.5                     # three values: huge tie groups
+    err[:, 4] = torch.rand((t,), generator=g, dtype=torch.float64) * 2.0 ** -20 + 1.0     # all keys share 20+ leading bits
+    err[:, 5] = torch.where(torch.rand((t,), generator=g) < 0.5, 1e-30, 1e30).double()    # two far-apart clusters
+    err[:, 6] = 0.0
+    err[: t // 4, 6] = 7.0                                                                # q75 on the boundary of a tie group
+    err[:, 7] = torch.rand((t,), generator=g, dtype=torch.float64)
+    err[:, 8] = torch.rand((t,), generator=g, dtype=torch.float64) ** 8                   # mass near zero, many exponents
+    err[:, 9] = torch.arange(t, dtype=torch.float64) * 1e-6                               # sorted input
+    err[:, 10] = torch.arange(t, 0, -1, dtype=torch.float64)                              # reverse sorted
+    err[:, 11] = torch.rand((t,), generator=g, dtype=torch.float64) * 1e-38               # fp32 denormal range
+    gt = err.float()                  # pred = 0, gt >= 0  ->  |pred - gt| = gt exactly (float32 values)
+    _scores, _anomaly, med_iqr = evaluate.anomaly_scores(pred, gt, device=gpu_device)
+    for i in range(n):
+        med, rng = score_oracle.err_median_and_iqr(pred[:, i].numpy(), gt[:, i].numpy())
+        np.testing.assert_array_equal(med_iqr[i].cpu().numpy(), np.array([med, rng]), err_msg=f"sensor {i}")
