@@ -28,7 +28,8 @@ static inline int gdn_cu_count() {
 }
 
 // gdn_forward_dense.hip: the matrix-core aggregation path (n <= 127, d = 64); x is fp32 or bf16 bits
-bool gdn_dense_supported(int n, int w, int d, int k);
+bool gdn_dense_supported(int n, int w, int d, int k);         // staged kernels: d = 64
+bool gdn_dense_fused_supported(int n, int w, int d, int k);   // fused kernel: d = 64 or 128
 int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int series_first, const float* lin_w,
                             const float* node_terms, const uint16_t* nbr, const float* gnn_bias,
                             const float* emb, const float* bn1, const float* bn2, const float* out_w,

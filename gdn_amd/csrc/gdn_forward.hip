@@ -1199,7 +1199,7 @@ extern "C" int gdn_forward_fused(const float* x, const float* lin_w, const float
   if (!x || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine ||
       !bn2_affine || !out_w || !out_b || !out)
     return GDN_ERR_ARG;
-  if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, w, d, k))
+  if (batch > 0 && gdn_use_dense_path() && gdn_dense_fused_supported(n, w, d, k))
     return gdn_dense_forward_fused(x, 0, 0, 0, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine, bn2_affine,
                                    out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
   return fused_gather(x, 0, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
@@ -1215,7 +1215,7 @@ extern "C" int gdn_forward_fused_series(const float* series, int series_len, int
       !bn2_affine || !out_w || !out_b || !out || series_len <= 0 || first < 0)
     return GDN_ERR_ARG;
   if ((long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;   // last window must fit
-  if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, w, d, k))
+  if (batch > 0 && gdn_use_dense_path() && gdn_dense_fused_supported(n, w, d, k))
     return gdn_dense_forward_fused(series, 0, series_len, first, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine,
                                    bn2_affine, out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
   Plan pl; int threads;
@@ -1288,7 +1288,7 @@ extern "C" int gdn_forward_fused_bf16(const uint16_t* x, const float* lin_w, con
   if (!x || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine || !bn2_affine ||
       !out_w || !out_b || !out || batch <= 0)
     return GDN_ERR_ARG;
-  if (gdn_use_dense_path() && gdn_dense_supported(n, w, d, k))
+  if (gdn_use_dense_path() && gdn_dense_fused_supported(n, w, d, k))
     return gdn_dense_forward_fused(x, 1, 0, 0, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine, bn2_affine,
                                    out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
   return fused_gather(x, 1, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,

@@ -35,6 +35,9 @@
 #include <mutex>
 #include <stdlib.h>
 
+int gdn_dense_fused_op_d128(int op, const void* args, int bf16, unsigned* plan_out, long long* bytes,
+                            hipStream_t st);   // gdn_forward_dense_d128.hip
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -445,10 +448,15 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_plan_kernel(const DArgs a, 
   k.each_word([&](int i, unsigned& wd) { lanes[i * T + threadIdx.x] = wd; });
 }
 
+#ifdef GDN_DENSE_EXTRA_DC   // d = 128: one workgroup per CU and the whole 512-register file per wave (the default
+#define GDN_FUSED_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))   // heuristic keeps 2 waves/SIMD where LDS allows, and spills)
+#else
+#define GDN_FUSED_ATTR
+#endif
 template <int NT, int DC, int WK, int SL, int FMT>
 // two workgroups per CU (2 waves per SIMD, <= 256 registers) where the constants fit; the long-list /
 // long-window variants take the whole register file (accumulator registers as spill space) at one
-__global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) void gdn_dense_fused_kernel(const DArgs a) {
+__global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) GDN_FUSED_ATTR void gdn_dense_fused_kernel(const DArgs a) {
   using C = DCfg<NT, DC, WK, SL, FMT>;
   using F = Fmt<FMT>;
   extern __shared__ uint4 smem_u4[];
@@ -679,6 +687,7 @@ __global__ __launch_bounds__(64 * NT, (NT >= 3 && SL <= 16 && WK == 1) ? 2 : 1) 
   GDN_STAMP(10)
 }
 
+#ifndef GDN_DENSE_EXTRA_DC   // the d = 128 translation unit instantiates the fused family only
 // ------------------------------------------------------------------ staged gather-aggregate (K8)
 // z[b] = alpha[b] . xlin[b] + bias for windows whose projected tile xlin[n, 64] and attention scalars
 // come from HBM (gdn_project_fwd): models/graph_layer.py:65-74,82-117.  Same softmax / scatter /
@@ -1047,6 +1056,8 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_project_kernel(const PArgs 
   }
 }
 
+#endif  // GDN_DENSE_EXTRA_DC
+
 // ------------------------------------------------------------------ host side
 struct OccKey {
   const void* fn;
@@ -1123,22 +1134,34 @@ int select_sl(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipS
   return GDN_ERR_UNSUPPORTED;
 }
 
-template <int NT, int FMT>
+template <int NT, int FMT, int DC>
 int select_wk(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipStream_t st) {
-  if (a.w <= 16) return select_sl<NT, 2, 1, FMT>(op, a, plan_out, bytes, st);
-  return select_sl<NT, 2, 2, FMT>(op, a, plan_out, bytes, st);
+  if (a.w <= 16) return select_sl<NT, DC, 1, FMT>(op, a, plan_out, bytes, st);
+  return select_sl<NT, DC, 2, FMT>(op, a, plan_out, bytes, st);
 }
 
-template <int FMT>
+template <int FMT, int DC>
 int select_nt(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipStream_t st) {
   switch ((a.n + 1 + 31) / 32) {
-    case 1: return select_wk<1, FMT>(op, a, plan_out, bytes, st);
-    case 2: return select_wk<2, FMT>(op, a, plan_out, bytes, st);
-    case 3: return select_wk<3, FMT>(op, a, plan_out, bytes, st);
-    case 4: return select_wk<4, FMT>(op, a, plan_out, bytes, st);
+    case 1: return select_wk<1, FMT, DC>(op, a, plan_out, bytes, st);
+    case 2: return select_wk<2, FMT, DC>(op, a, plan_out, bytes, st);
+    case 3: return select_wk<3, FMT, DC>(op, a, plan_out, bytes, st);
+    case 4: return select_wk<4, FMT, DC>(op, a, plan_out, bytes, st);
   }
   return GDN_ERR_UNSUPPORTED;
 }
+
+#ifdef GDN_DENSE_EXTRA_DC
+}  // namespace
+// Entry of the extra translation unit (gdn_forward_dense_d128.hip): the fused family at d = 32 * GDN_DENSE_EXTRA_DC.
+// `args` is the DArgs of the main unit (same definition, compiled from the same text).
+int gdn_dense_fused_op_d128(int op, const void* args, int bf16, unsigned* plan_out, long long* bytes,
+                            hipStream_t st) {
+  const DArgs& a = *static_cast<const DArgs*>(args);
+  return bf16 ? select_nt<FMT_BF16, GDN_DENSE_EXTRA_DC>(op, a, plan_out, bytes, st)
+              : select_nt<FMT_F16, GDN_DENSE_EXTRA_DC>(op, a, plan_out, bytes, st);
+}
+#else
 
 template <int NT, int SL, int FMT, bool WANT_ALPHA>
 int launch_attn(const KArgs& a, hipStream_t stream) {
@@ -1207,9 +1230,18 @@ int gdn_dense_attn_aggregate(const void* xlin, int is_bf16, const float* s_i, co
   return alpha ? attn_select_nt<FMT_F16, true>(a, stream) : attn_select_nt<FMT_F16, false>(a, stream);
 }
 
-// Shapes the dense matrix-core path takes: n <= 127, d = 64, w <= 32, list pitch <= 64 (k <= 63).
+// Shapes the dense matrix-core path takes: n <= 127, w <= 32, list pitch <= 64 (k <= 63); d = 64 for the
+// staged kernels, d = 64 or 128 for the fused one.
 bool gdn_dense_supported(int n, int w, int d, int k) {
   return n >= 1 && n <= 127 && d == 64 && w >= 1 && w <= 32 && k >= 1 && k <= n && gdn_nbr_pitch(k) <= 64;
+}
+bool gdn_dense_fused_supported(int n, int w, int d, int k) {
+  return gdn_dense_supported(n, w, 64, k) && (d == 64 || d == 128);
+}
+
+static int fused_dispatch(int op, const DArgs& a, int bf16, unsigned* plan_out, long long* bytes, hipStream_t st) {
+  if (a.d == 128) return gdn_dense_fused_op_d128(op, &a, bf16, plan_out, bytes, st);
+  return bf16 ? select_nt<FMT_BF16, 2>(op, a, plan_out, bytes, st) : select_nt<FMT_F16, 2>(op, a, plan_out, bytes, st);
 }
 
 int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int series_first, const float* lin_w,
@@ -1217,14 +1249,13 @@ int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int se
                             const float* emb, const float* bn1, const float* bn2, const float* out_w,
                             const float* out_b, int batch, int n, int w, int d, int k, float* out,
                             hipStream_t stream) {
-  if (!gdn_dense_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
+  if (!gdn_dense_fused_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
   DArgs a = {};
   a.x = x; a.series_len = series_len; a.series_first = series_first;
   a.batch = batch; a.n = n; a.w = w; a.pitch = gdn_nbr_pitch(k); a.d = d;
   a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.gnn_bias = gnn_bias; a.emb = emb;
   a.bn1 = bn1; a.bn2 = bn2; a.out_w = out_w; a.out_b = out_b; a.out = out;
-  return x_is_bf16 ? select_nt<FMT_BF16>(DOP_LAUNCH, a, nullptr, nullptr, stream)
-                   : select_nt<FMT_F16>(DOP_LAUNCH, a, nullptr, nullptr, stream);
+  return fused_dispatch(DOP_LAUNCH, a, x_is_bf16, nullptr, nullptr, stream);
 }
 
 #ifdef GDN_STAMPS
@@ -1235,12 +1266,11 @@ extern "C" int gdn_debug_read_stamps(unsigned long long* host_out) {
 
 // ---- plans (C ABI: include/gdn_hip.h) -----------------------------------------------------------------
 extern "C" long long gdn_fused_plan_bytes(int n, int w, int d, int k, int bf16_storage) {
-  if (!gdn_dense_supported(n, w, d, k)) return 0;
+  if (!gdn_dense_fused_supported(n, w, d, k)) return 0;
   DArgs a = {};
   a.n = n; a.w = w; a.d = d; a.pitch = gdn_nbr_pitch(k);
   long long bytes = 0;
-  const int rc = bf16_storage ? select_nt<FMT_BF16>(DOP_PLAN_BYTES, a, nullptr, &bytes, nullptr)
-                              : select_nt<FMT_F16>(DOP_PLAN_BYTES, a, nullptr, &bytes, nullptr);
+  const int rc = fused_dispatch(DOP_PLAN_BYTES, a, bf16_storage, nullptr, &bytes, nullptr);
   return rc == GDN_OK ? bytes : 0;
 }
 
@@ -1252,27 +1282,25 @@ extern "C" int gdn_fused_plan_build(const float* lin_w, const float* node_terms,
   if (!lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine || !bn2_affine || !out_w ||
       !out_b || !plan)
     return GDN_ERR_ARG;
-  if (!gdn_dense_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
+  if (!gdn_dense_fused_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
   DArgs a = {};
   a.n = n; a.w = w; a.d = d; a.pitch = gdn_nbr_pitch(k);
   a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.gnn_bias = gnn_bias; a.emb = emb;
   a.bn1 = bn1_affine; a.bn2 = bn2_affine; a.out_w = out_w; a.out_b = out_b;
   unsigned* p = reinterpret_cast<unsigned*>(plan);
-  return bf16_storage ? select_nt<FMT_BF16>(DOP_PLAN_BUILD, a, p, nullptr, (hipStream_t)stream)
-                      : select_nt<FMT_F16>(DOP_PLAN_BUILD, a, p, nullptr, (hipStream_t)stream);
+  return fused_dispatch(DOP_PLAN_BUILD, a, bf16_storage, p, nullptr, (hipStream_t)stream);
 }
 
 static int fused_with_plan(const void* x, int series_len, int first, const void* plan, int batch, int n, int w,
                            int d, int k, int bf16_storage, float* out, void* stream) {
   if (!x || !plan || !out) return GDN_ERR_ARG;
   if (batch <= 0 || n <= 0) return GDN_ERR_ARG;
-  if (!gdn_dense_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
+  if (!gdn_dense_fused_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
   DArgs a = {};
   a.x = x; a.series_len = series_len; a.series_first = first;
   a.batch = batch; a.n = n; a.w = w; a.pitch = gdn_nbr_pitch(k); a.d = d;
   a.out = out; a.plan = reinterpret_cast<const unsigned*>(plan);
-  return bf16_storage ? select_nt<FMT_BF16>(DOP_LAUNCH, a, nullptr, nullptr, (hipStream_t)stream)
-                      : select_nt<FMT_F16>(DOP_LAUNCH, a, nullptr, nullptr, (hipStream_t)stream);
+  return fused_dispatch(DOP_LAUNCH, a, bf16_storage, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int gdn_forward_fused_plan(const void* x, const void* plan, int batch, int n, int w, int d, int k,
@@ -1285,3 +1313,4 @@ extern "C" int gdn_forward_fused_series_plan(const float* series, int series_len
   if (series_len <= 0 || first < 0 || (long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;
   return fused_with_plan(series, series_len, first, plan, batch, n, w, d, k, 0, out, stream);
 }
+#endif  // GDN_DENSE_EXTRA_DC

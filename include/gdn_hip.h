@@ -28,7 +28,8 @@
  *     MSL/SMAP/PSM sets); beyond that gdn_attn_aggregate_bwd_ws keeps the tables in global memory and
  *     only the tile must fit (n <= ~600 at d = 64: the 512-sensor / k = 64 stress shape trains);
  *   matrix-core ("dense") kernels — gdn_forward_fused, gdn_project_fwd, gdn_attn_aggregate_fwd pick them
- *     by themselves for n <= 127, d = 64, w <= 32, k <= 63; the bf16-storage entry points exist only there;
+ *     by themselves for n <= 127, d = 64, w <= 32, k <= 63 (gdn_forward_fused also at d = 128); the staged
+ *     bf16-storage entry points exist only there;
  * anything else returns GDN_ERR_UNSUPPORTED (never a silent fallback).
  */
 #ifndef GDN_HIP_H
@@ -269,7 +270,7 @@ int gdn_forward_fused_series(const float* series, int series_len, int first, con
                              int batch, int n, int w, int d, int k, float* out, void* stream);
 
 /* ---- plans: the fused forward with its per-launch constants precomputed -------------
- * For shapes on the matrix-core path (n <= 127, d = 64, w <= 32, k <= 63) everything a
+ * For shapes on the matrix-core path (n <= 127, d = 64 or 128, w <= 32, k <= 63) everything a
  * workgroup of gdn_forward_fused derives from the parameters and the sensor graph (list
  * offsets, split weight operands, folded BatchNorm / embedding factors) can be computed
  * once per parameter update into a caller-owned device buffer, the PLAN; launches that are

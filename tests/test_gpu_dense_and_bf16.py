@@ -223,11 +223,11 @@ def test_bf16_storage_at_baseline_config2_batch_512(gpu_device):
     np.testing.assert_allclose(out.cpu().numpy(), data["eval_out"], atol=2e-3, rtol=0)
 
 
-@pytest.mark.parametrize("n,w,k,d,b", [(512, 30, 64, 64, 6), (300, 12, 20, 64, 5), (127, 15, 30, 128, 9),
+@pytest.mark.parametrize("n,w,k,d,b", [(512, 30, 64, 64, 6), (300, 12, 20, 64, 5), (127, 15, 30, 32, 9),
                                        (200, 40, 90, 32, 4)],
-                         ids=["config4_n512_k64_w30", "n300_w12_k20", "n127_d128", "n200_w40_k90_d32"])
+                         ids=["config4_n512_k64_w30", "n300_w12_k20", "n127_d32", "n200_w40_k90_d32"])
 def test_bf16_storage_fused_forward_on_the_gather_path(n, w, k, d, b, gpu_device):
-    """Shapes the matrix-core kernels do not take (n > 127, d != 64, w > 32): the fp32 row-gather kernel reads
+    """Shapes the matrix-core kernels do not take (n > 127, d not 64 / 128, w > 32): the fp32 row-gather kernel reads
     bf16 windows and rounds the LDS-resident projected tile to bf16 — the same storage semantics, the
     oracle's rounding point exactly.  First case = BASELINE configs[4] as worded (512 sensors, top-k 64,
     W=30, bf16)."""
@@ -243,6 +243,31 @@ def test_bf16_storage_fused_forward_on_the_gather_path(n, w, k, d, b, gpu_device
     np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4, rtol=0)
     assert not torch.equal(out, out32)                       # the tile really was rounded
     assert float((out - out32).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("n,w,k,b", [(127, 15, 30, 9), (40, 30, 16, 33), (64, 5, 63, 4), (100, 17, 40, 700)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_dense_fused_forward_at_d128(n, w, k, b, bf16, gpu_device):
+    """d = 128 (the paper's WADI width): the fused matrix-core kernel with four 32-column blocks
+    (gdn_forward_dense_d128.hip) — planned launch (GDN.forward), plain entry point, float64 oracle, and the
+    fp32 row-gather kernel on the same inputs."""
+    from gdn_amd import ops
+    model = random_params(n, w, k, 128, seed=6)
+    p = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    x = torch.rand((b, n, w), generator=torch.Generator().manual_seed(2))
+    xin = (x.bfloat16() if bf16 else x).to(gpu_device)
+    with torch.no_grad():
+        out = model(xin, None)
+    c = model._constants()
+    assert c.plans[bf16] is not None                       # the matrix-core path took it
+    gnn, lin = model.gnn_layers[0].gnn, model.out_layer.mlp[0]
+    plain = ops.forward_fused(xin, gnn.lin.weight, c.terms, c.graph, gnn.bias, model.embedding.weight, c.bn1, c.bn2,
+                              lin.weight, lin.bias)
+    np.testing.assert_allclose(out.cpu().numpy(), plain.cpu().numpy(), atol=3e-7, rtol=0)
+    ref = gdn_oracle.forward(f64_params(p), xin.cpu().double(), k, graph=model.learned_graph.cpu(),
+                             storage="bf16" if bf16 else "fp32")
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-4 if bf16 else 2e-6, rtol=0)
 
 
 def test_bf16_staged_kernels_refuse_shapes_outside_the_matrix_core_path(gpu_device):
