@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -29,10 +29,10 @@ SIGNATURES = {
     "gdn_head_train_workspace_bytes": [_c_int, _c_int],
     "gdn_head_train_stats_bytes": [_c_int],
     "gdn_head_train_bwd": [_p] * 10 + [_c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 10,
-    "gdn_head_train_fwd_rng": [_p] * 9 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 9,
-    "gdn_head_train_bwd_rng": [_p] * 9 + [_c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 10,
-    "gdn_head_train_fwd_act": [_p] * 8 + [_c_float, _p, _c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 9,
-    "gdn_head_train_bwd_act": [_p] * 9 + [_c_float, _p, _c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 8,
+    "gdn_head_train_fwd_rng": [_p] * 9 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 8 + [_c_int, _p],
+    "gdn_head_train_bwd_rng": [_p] * 9 + [_c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 9 + [_c_int, _p],
+    "gdn_head_train_fwd_act": [_p] * 8 + [_c_float, _p, _c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 8 + [_c_int, _p],
+    "gdn_head_train_bwd_act": [_p] * 9 + [_c_float, _p, _c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 7 + [_c_int, _p],
     "gdn_mlp_train_saved_bytes": [_c_int] * 4,
     "gdn_mlp_train_workspace_bytes": [_c_int] * 4,
     "gdn_mlp_train_fwd": [_p] * 8 + [_c_int] * 4 + [_p] * 4,

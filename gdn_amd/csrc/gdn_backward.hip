@@ -479,11 +479,15 @@ __global__ __launch_bounds__(256) void gdn_terms_bwd_kernel(
   // column c is handled by the 256/d threads tid = c, c+d, ...: strided partial sums, then an LDS reduce
   const int c = tid % d, g = tid / d, groups = 256 / d;
   float si = 0.f, sj = 0.f, ei = 0.f, ej = 0.f;
+  // (independent loads, eight iterations in flight: left rolled, the two loops were ~35 dependent L2 round
+  // trips and the kernel took 15 us of a 218 us training step)
+#pragma unroll 8
   for (int q = g; q < w; q += groups) {
     const float lw = lin_w[c * w + q];
     si = fmaf(lw, d_a[q], si);
     sj = fmaf(lw, d_a[GDN_A_PITCH + q], sj);
   }
+#pragma unroll 8
   for (int s = g; s < n; s += groups) {
     const float ev = emb[(size_t)s * d + c];
     ei = fmaf(ev, d_c[s], ei);

@@ -39,10 +39,9 @@ __device__ __forceinline__ void emit_list(const int* __restrict__ rank_of, int i
 
 // One workgroup per target sensor i: reference models/GDN.py:148-159 (cosine row, top-k),
 // then the list form of :161-163.
-__global__ __launch_bounds__(256) void gdn_graph_kernel(
+__device__ __forceinline__ void graph_row(
     const float* __restrict__ emb, int n, int d, int k, int pitch, int64_t* __restrict__ topk_idx,
-    uint16_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ cos_out) {
-  extern __shared__ float smem_graph[];
+    uint16_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ cos_out, float* smem_graph) {
   float* cosrow = smem_graph;                            // [n]
   int* rank_of = reinterpret_cast<int*>(smem_graph + n);  // [n]
   const int i = blockIdx.x;
@@ -82,6 +81,13 @@ __global__ __launch_bounds__(256) void gdn_graph_kernel(
   emit_list(rank_of, i, n, k, pitch, nbr + (size_t)i * pitch, deg + i);
 }
 
+__global__ __launch_bounds__(256) void gdn_graph_kernel(
+    const float* __restrict__ emb, int n, int d, int k, int pitch, int64_t* __restrict__ topk_idx,
+    uint16_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ cos_out) {
+  extern __shared__ float smem_graph[];
+  graph_row(emb, n, d, k, pitch, topk_idx, nbr, deg, cos_out, smem_graph);
+}
+
 // Same list build from a given [n,k] top-k table.  The table is caller data: entries outside
 // [0, n) and repeated entries are dropped (first occurrence wins), so every slot below deg is
 // written and deg counts what was kept — the aggregation kernels never see an unwritten index.
@@ -112,11 +118,11 @@ __global__ __launch_bounds__(256) void gdn_graph_from_topk_kernel(
 }
 
 // a_i = lin^T att_i, a_j = lin^T att_j (zero padded to 64), c_i[s] = v_s.att_em_i, c_j[s].
-__global__ __launch_bounds__(256) void gdn_node_terms_kernel(
+__device__ __forceinline__ void node_terms_block(
     const float* __restrict__ lin_w, const float* __restrict__ att_i, const float* __restrict__ att_j,
     const float* __restrict__ att_em_i, const float* __restrict__ att_em_j,
-    const float* __restrict__ emb, int n, int d, int w, float* __restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* __restrict__ emb, int n, int d, int w, float* __restrict__ out, int block) {
+  const int t = block * blockDim.x + threadIdx.x;
   if (t < 2 * GDN_A_PITCH) {
     const int col = t % GDN_A_PITCH;
     const float* att = t < GDN_A_PITCH ? att_i : att_j;
@@ -132,6 +138,25 @@ __global__ __launch_bounds__(256) void gdn_node_terms_kernel(
     for (int r = 0; r < d; ++r) acc = fmaf(emb[(size_t)s * d + r], att[r], acc);
     out[t] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void gdn_node_terms_kernel(
+    const float* __restrict__ lin_w, const float* __restrict__ att_i, const float* __restrict__ att_j,
+    const float* __restrict__ att_em_i, const float* __restrict__ att_em_j,
+    const float* __restrict__ emb, int n, int d, int w, float* __restrict__ out) {
+  node_terms_block(lin_w, att_i, att_j, att_em_i, att_em_j, emb, n, d, w, out, blockIdx.x);
+}
+
+// One launch for the two parameter-only prologues of a training step (every dependent launch inside a
+// captured step costs ~5 us whatever it does): blocks [0, n) build the graph rows, the rest the folded terms.
+__global__ __launch_bounds__(256) void gdn_graph_terms_kernel(
+    const float* __restrict__ emb, int n, int d, int k, int pitch, int64_t* __restrict__ topk_idx,
+    uint16_t* __restrict__ nbr, int32_t* __restrict__ deg, const float* __restrict__ lin_w,
+    const float* __restrict__ att_i, const float* __restrict__ att_j, const float* __restrict__ att_em_i,
+    const float* __restrict__ att_em_j, int w, float* __restrict__ terms) {
+  extern __shared__ float smem_graph[];
+  if ((int)blockIdx.x < n) graph_row(emb, n, d, k, pitch, topk_idx, nbr, deg, nullptr, smem_graph);
+  else node_terms_block(lin_w, att_i, att_j, att_em_i, att_em_j, emb, n, d, w, terms, (int)blockIdx.x - n);
 }
 
 __global__ void gdn_bn_fold_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
@@ -178,6 +203,21 @@ extern "C" int gdn_node_terms(const float* lin_w, const float* att_i, const floa
   hipLaunchKernelGGL(gdn_node_terms_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, lin_w, att_i, att_j, att_em_i, att_em_j, emb, n, d, w,
                      node_terms);
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_topk_graph_terms(const float* emb, int n, int d, int k, int64_t* topk_idx, uint16_t* nbr,
+                                    int32_t* deg, const float* lin_w, const float* att_i, const float* att_j,
+                                    const float* att_em_i, const float* att_em_j, int w, float* node_terms,
+                                    void* stream) {
+  if (!emb || !topk_idx || !nbr || !deg || !lin_w || !att_i || !att_j || !att_em_i || !att_em_j || !node_terms ||
+      n <= 0 || d <= 0 || k <= 0 || w <= 0)
+    return GDN_ERR_ARG;
+  if (k > n || n > 4096 || k + 1 > 1024 || (d & 3) || w > GDN_MAX_W) return GDN_ERR_UNSUPPORTED;
+  const int total = 2 * GDN_A_PITCH + 2 * n;
+  hipLaunchKernelGGL(gdn_graph_terms_kernel, dim3(n + (total + 255) / 256), dim3(256), 2 * n * sizeof(float),
+                     (hipStream_t)stream, emb, n, d, k, gdn_nbr_pitch(k), topk_idx, nbr, deg, lin_w, att_i, att_j,
+                     att_em_i, att_em_j, w, node_terms);
   return gdn_launch_status();
 }
 

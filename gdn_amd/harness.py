@@ -15,6 +15,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -746,8 +747,9 @@ class NativeTrainStep:
             xlin=torch.empty((bn_rows, d), **f32), s_i=torch.empty((bn_rows,), **f32), s_j=torch.empty((bn_rows,), **f32),
             z=torch.empty((bn_rows, d), **f32), alpha=torch.empty((bn_rows, pitch), **f32),
             out=torch.empty((batch, n), **f32), d_out=torch.empty((batch, n), **f32),
-            stats=torch.empty((lib.gdn_head_train_stats_bytes(d) // 8,), dtype=torch.float64, device=dev),
-            head_ws=torch.empty((lib.gdn_head_train_workspace_bytes(n, d) // 8,), dtype=torch.float64, device=dev),
+            # zero-filled ONCE: the head kernels are told so (buffers_zeroed = 1) and leave them zeroed after every backward
+            stats=torch.zeros((lib.gdn_head_train_stats_bytes(d) // 8,), dtype=torch.float64, device=dev),
+            head_ws=torch.zeros((lib.gdn_head_train_workspace_bytes(n, d) // 8,), dtype=torch.float64, device=dev),
             d_z=torch.empty((bn_rows, d), **f32), d_xlin=torch.empty((bn_rows, d), **f32),
             d_si=torch.empty((bn_rows,), **f32), d_sj=torch.empty((bn_rows,), **f32),
             proj_ws=torch.empty((lib.gdn_project_bwd_workspace_bytes(n, w, d) // 4,), **f32),
@@ -763,6 +765,8 @@ class NativeTrainStep:
                 act=torch.empty((bn_rows, d), **f32), d_act=torch.empty((bn_rows, d), **f32),
                 mlp_saved=torch.empty((lib.gdn_mlp_train_saved_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev),
                 mlp_ws=torch.empty((lib.gdn_mlp_train_workspace_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev))
+        self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        self._fork = os.environ.get("GDN_TRAIN_FORK", "0") == "1"
         self.use_graph = use_graph
         self._graphs = None
         self._split = world()[1] > 1 if split is None else bool(split)
@@ -794,13 +798,21 @@ class NativeTrainStep:
         p_drop = float(m.dp.p) if m.dp.training else 0.0
         rng = self.state.data_ptr()
         pt = {key: t.data_ptr() for key, t in ws.items()}
-        # graph + folded attention terms of THIS step's parameters (models/GDN.py:145-165, graph_layer.py:94-104)
-        call("gdn_topk_graph", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], None, st)
-        call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], st)
+        # graph + folded attention terms of THIS step's parameters (models/GDN.py:145-165, graph_layer.py:94-104).
+        # Three independent chains, forked onto side streams (inside the captured graph they become parallel
+        # branches): [top-k graph] | [folded terms -> projection] | [reverse lists, needed by the backward only]
+        main = torch.cuda.current_stream()
+        side, side2 = self._side if self._fork else (main, main)
+        side.wait_stream(main)
+        s2 = side.cuda_stream
         call("gdn_node_terms", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
-             P("embedding.weight"), n, d, w, pt["terms"], st)
+             P("embedding.weight"), n, d, w, pt["terms"], s2)
         call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
-             pt["s_j"], st)
+             pt["s_j"], s2)
+        call("gdn_topk_graph", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], None, st)
+        side2.wait_stream(main)
+        call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], side2.cuda_stream)
+        main.wait_stream(side)
         call("gdn_attn_aggregate_fwd", pt["xlin"], pt["s_i"], pt["s_j"], pt["nbr"], pt["deg"], P(g + "bias"), b, n, d, k,
              pt["z"], pt["alpha"], st)
         m1, rm1, rv1, nb1 = self._bn_run(bn1)
@@ -812,7 +824,7 @@ class NativeTrainStep:
         if self._mlp is None:
             lw, lb = "out_layer.mlp.0.weight", "out_layer.mlp.0.bias"
             call("gdn_head_train_fwd_rng", pt["z"], P("embedding.weight"), *bnp, P(lw), P(lb), rng, p_drop, b, n, d,
-                 *eps, *run, pt["stats"], pt["out"], st)
+                 *eps, *run, pt["stats"], pt["out"], 1, st)
         else:
             # out_layer_num > 1: head passes up to the dropped-out activation, then the MLP on the matrix cores
             h, layers, bns = self._mlp
@@ -822,7 +834,7 @@ class NativeTrainStep:
             lw, lb = f"out_layer.mlp.{3 * (layers - 1)}.weight", f"out_layer.mlp.{3 * (layers - 1)}.bias"
             runs = [self._bn_run(bn) for bn in bns]
             call("gdn_head_train_fwd_act", pt["z"], P("embedding.weight"), *bnp, None, None, 1.0, rng, p_drop, b, n, d,
-                 *eps, *run, pt["stats"], pt["act"], st)
+                 *eps, *run, pt["stats"], pt["act"], 1, st)
             call("gdn_mlp_train_fwd", pt["act"], arr([P(nm) for nm in names]),
                  arr([q for r in runs for q in (r[1], r[2])]), arr([r[3] for r in runs]),
                  (ctypes.c_float * len(bns))(*[float(bn.eps) for bn in bns]),
@@ -832,12 +844,13 @@ class NativeTrainStep:
         # backward: gradients land in their slots of flat_g
         if self._mlp is None:
             call("gdn_head_train_bwd_rng", pt["d_out"], pt["z"], P("embedding.weight"), *bnp, P(lw), rng, p_drop,
-                 pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, G(lw), G(lb), st)
+                 pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, G(lw), G(lb), 1, st)
         else:
             call("gdn_mlp_train_bwd", pt["d_out"], pt["act"], arr([P(nm) for nm in names]), P(lw), b * n, d, h, layers,
                  pt["mlp_saved"], pt["mlp_ws"], arr([G(nm) for nm in names]), G(lw), G(lb), pt["d_act"], st)
             call("gdn_head_train_bwd_act", pt["d_act"], pt["z"], P("embedding.weight"), *bnp, None, None, 1.0, rng,
-                 p_drop, pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, st)
+                 p_drop, pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, 1, st)
+        main.wait_stream(side2)                      # reverse lists
         call("gdn_attn_aggregate_bwd", pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
              pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), st)     # slot cleared by Adam
         call("gdn_project_bwd", self.x.data_ptr(), pt["d_xlin"], pt["d_si"], pt["d_sj"], b, n, w, d, pt["proj_ws"],

@@ -264,7 +264,7 @@ def head_train_fwd_act(z, emb, bn1, bn2, mask, batch: int, mask_scale: float = 1
     _lib.call("gdn_head_train_fwd_act", _ptr(z), _ptr(_chk(emb.detach())), _ptr(_chk(bn1.weight.detach())),
               _ptr(_chk(bn1.bias.detach())), _ptr(_chk(bn2.weight.detach())), _ptr(_chk(bn2.bias.detach())),
               mptr, kptr, kscale, None, 0.0, batch, n, d, float(bn1.eps), float(bn2.eps), m1, m2, _ptr(rm1), _ptr(rv1),
-              _ptr(nb1), _ptr(rm2), _ptr(rv2), _ptr(nb2), _ptr(stats), _ptr(act), _stream())
+              _ptr(nb1), _ptr(rm2), _ptr(rv2), _ptr(nb2), _ptr(stats), _ptr(act), 0, _stream())
     return act, stats
 
 
@@ -283,7 +283,7 @@ def head_train_bwd_act(d_act, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, mask, stats, e
     mptr, kptr, kscale = _mask_args(mask, z.numel(), mask_scale)
     _lib.call("gdn_head_train_bwd_act", _ptr(d_act), _ptr(z), _ptr(_chk(emb)), _ptr(_chk(bn1_w)), _ptr(_chk(bn1_b)),
               _ptr(_chk(bn2_w)), _ptr(_chk(bn2_b)), mptr, kptr, kscale, None, 0.0, _ptr(stats), batch, n, d, eps1, eps2,
-              _ptr(ws), _ptr(d_z), _ptr(d_emb), _ptr(g1w), _ptr(g1b), _ptr(g2w), _ptr(g2b), _stream())
+              _ptr(ws), _ptr(d_z), _ptr(d_emb), _ptr(g1w), _ptr(g1b), _ptr(g2w), _ptr(g2b), 0, _stream())
     return d_z, d_emb, g1w, g1b, g2w, g2b
 
 

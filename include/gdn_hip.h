@@ -46,7 +46,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 14
+#define GDN_ABI_VERSION 15
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -180,13 +180,20 @@ int gdn_head_train_fwd_rng(const float* z, const float* emb, const float* bn1_w,
                            int batch, int n, int d, float eps1, float eps2, float momentum1,
                            float momentum2, float* running_mean1, float* running_var1,
                            long long* batches1, float* running_mean2, float* running_var2,
-                           long long* batches2, double* stats, float* out, void* stream);
+                           long long* batches2, double* stats, float* out, int buffers_zeroed,
+                           void* stream);
 int gdn_head_train_bwd_rng(const float* d_out, const float* z, const float* emb, const float* bn1_w,
                            const float* bn1_b, const float* bn2_w, const float* bn2_b,
                            const float* lin_w, const long long* rng_seed_step, float p_drop,
                            const double* stats, int batch, int n, int d, float eps1, float eps2,
                            double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
-                           float* d_bn2_w, float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream);
+                           float* d_bn2_w, float* d_bn2_b, float* d_lin_w, float* d_lin_b,
+                           int buffers_zeroed, void* stream);
+/* buffers_zeroed (the _rng and _act entry points): 0 = the call zero-fills its accumulators itself (a
+ * memset launch each in forward and backward); 1 = the caller guarantees `stats` (forward) / the first
+ * gdn_head_train_stats_bytes-style block of `workspace` (backward) are zero on entry, and the backward
+ * leaves BOTH zeroed again when it finishes — a training loop that zero-fills them once never pays the two
+ * memset launches (~5 us each at 512 windows).                                                          */
 
 /* ---- train-mode OutLayer MLP, out_layer_num > 1 (models/GDN.py:27-56 under model.train()) ----------
  * The head passes above end at the [B*n, d] activation after dropout (forward: `act`) / start from its
@@ -199,14 +206,14 @@ int gdn_head_train_fwd_act(const float* z, const float* emb, const float* bn1_w,
                            float eps2, float momentum1, float momentum2, float* running_mean1,
                            float* running_var1, long long* batches1, float* running_mean2,
                            float* running_var2, long long* batches2, double* stats, float* act,
-                           void* stream);
+                           int buffers_zeroed, void* stream);
 int gdn_head_train_bwd_act(const float* d_act, const float* z, const float* emb, const float* bn1_w,
                            const float* bn1_b, const float* bn2_w, const float* bn2_b,
                            const float* mask, const uint8_t* keep, float keep_scale,
                            const long long* rng_seed_step, float p_drop,
                            const double* stats, int batch, int n, int d, float eps1, float eps2,
                            double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
-                           float* d_bn2_w, float* d_bn2_b, void* stream);
+                           float* d_bn2_w, float* d_bn2_b, int buffers_zeroed, void* stream);
 /* The MLP itself: Y_l = A_l W_l^T + b_l, A_{l+1} = relu(BatchNorm_train(Y_l)) for l = 0..layers-2 (A_0 = act
  * [rows, d_in]), out = A_{layers-1} w_o + b_o — replaces OutLayer.forward (models/GDN.py:47-56) and the
  * autograd graph behind train.py:72.  fp32 matrix cores (exact fp32 products), batch statistics and every
