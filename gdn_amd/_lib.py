@@ -37,6 +37,7 @@ SIGNATURES = {
     "gdn_mlp_train_workspace_bytes": [_c_int] * 4,
     "gdn_mlp_train_fwd": [_p] * 8 + [_c_int] * 4 + [_p] * 4,
     "gdn_mlp_train_bwd": [_p] * 4 + [_c_int] * 4 + [_p] * 7,
+    "gdn_topk_graph_terms": [_p, _c_int, _c_int, _c_int] + [_p] * 8 + [_c_int, _p, _p],
     "gdn_adam_step": [_p] * 5 + [_c_int] + [ctypes.c_double] * 6 + [_c_int, _c_int, _p],
     "gdn_terms_bwd_acc": [_p] * 8 + [_c_int] * 3 + [_p] * 6 + [_c_int, _p],
     "gdn_mse_workspace_bytes": [],

@@ -799,20 +799,30 @@ class NativeTrainStep:
         rng = self.state.data_ptr()
         pt = {key: t.data_ptr() for key, t in ws.items()}
         # graph + folded attention terms of THIS step's parameters (models/GDN.py:145-165, graph_layer.py:94-104).
-        # Three independent chains, forked onto side streams (inside the captured graph they become parallel
-        # branches): [top-k graph] | [folded terms -> projection] | [reverse lists, needed by the backward only]
+        # GDN_TRAIN_FORK=1: three independent chains forked onto side streams (parallel branches of the captured
+        # graph): [top-k graph] | [folded terms -> projection] | [reverse lists, needed by the backward only] —
+        # measured SLOWER than the serial chain inside a HIP graph (0.235 vs 0.218 ms), so off by default
         main = torch.cuda.current_stream()
-        side, side2 = self._side if self._fork else (main, main)
-        side.wait_stream(main)
-        s2 = side.cuda_stream
-        call("gdn_node_terms", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
-             P("embedding.weight"), n, d, w, pt["terms"], s2)
-        call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
-             pt["s_j"], s2)
-        call("gdn_topk_graph", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], None, st)
-        side2.wait_stream(main)
-        call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], side2.cuda_stream)
-        main.wait_stream(side)
+        if self._fork:
+            side, side2 = self._side
+            side.wait_stream(main)
+            s2 = side.cuda_stream
+            call("gdn_node_terms", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
+                 P("embedding.weight"), n, d, w, pt["terms"], s2)
+            call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
+                 pt["s_j"], s2)
+            call("gdn_topk_graph", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], None, st)
+            side2.wait_stream(main)
+            call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], side2.cuda_stream)
+            main.wait_stream(side)
+        else:
+            side2 = main
+            # graph rows and folded terms in one launch (independent work, one launch less on the critical path)
+            call("gdn_topk_graph_terms", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], P(g + "lin.weight"),
+                 P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"), w, pt["terms"], st)
+            call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], st)
+            call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
+                 pt["s_j"], st)
         call("gdn_attn_aggregate_fwd", pt["xlin"], pt["s_i"], pt["s_j"], pt["nbr"], pt["deg"], P(g + "bias"), b, n, d, k,
              pt["z"], pt["alpha"], st)
         m1, rm1, rv1, nb1 = self._bn_run(bn1)

@@ -81,6 +81,13 @@ int gdn_node_terms(const float* lin_w, const float* att_i, const float* att_j,
                    const float* att_em_i, const float* att_em_j, const float* emb,
                    int n, int d, int w, float* node_terms, void* stream);
 
+/* gdn_topk_graph + gdn_node_terms as ONE launch (a training step rebuilds both from the parameters it is about
+ * to use; they are independent of each other): same outputs, no cos_out.                              */
+int gdn_topk_graph_terms(const float* emb, int n, int d, int k, int64_t* topk_idx, uint16_t* nbr,
+                         int32_t* deg, const float* lin_w, const float* att_i, const float* att_j,
+                         const float* att_em_i, const float* att_em_j, int w, float* node_terms,
+                         void* stream);
+
 /* Eval-mode BatchNorm1d folded to y = x*scale + shift (models/GDN.py:77, :179 under
  * model.eval()): scale = weight/sqrt(var+eps), shift = bias - mean*scale.
  * affine receives [scale(c) | shift(c)].                                               */
