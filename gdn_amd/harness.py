@@ -349,10 +349,13 @@ class ShardedEvaluator:
         for w in works:
             w.wait()
         if self.n_mine:
-            extra = {"ws": self._sel_ws, "out": self._sel_out} if self._sel_ws is not None else {}
-            mi = self.backend.select(self.recv.reshape(-1), self.nchunks * self.size, self.n_mine, self.pitch,
-                                     self.total, **extra)
-            self.pub[: self.n_mine * 2] = mi.reshape(-1)
+            if self._sel_ws is not None:        # the select writes straight into the row this rank publishes
+                self.backend.select(self.recv.reshape(-1), self.nchunks * self.size, self.n_mine, self.pitch, self.total,
+                                    ws=self._sel_ws, out=self.pub[: self.n_mine * 2].view(self.n_mine, 2))
+            else:
+                mi = self.backend.select(self.recv.reshape(-1), self.nchunks * self.size, self.n_mine, self.pitch,
+                                         self.total)
+                self.pub[: self.n_mine * 2] = mi.reshape(-1)
         if self.take:
             self.pub[self.cap * 2:].view(2, 3, self.n)[0, 3 - self.take:] = self.pred[self.t - self.take:]
         dist.all_gather_into_tensor(self.gathered, self.pub, group=self.group)
