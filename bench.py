@@ -179,7 +179,8 @@ def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
 
 def train_step_line(device, n, w, batch, steps=50):
     """Extra (not the headline): one optimisation step of the reference's train() (train.py:52-66) at the
-    same shape — HIP forward/backward, HIP train-mode head, fused Adam — replayed from one HIP graph."""
+    same shape — harness.NativeTrainStep: HIP forward/backward, in-kernel dropout draw, gdn_adam_step over flat
+    buffers — replayed from one HIP graph."""
     from gdn_amd.harness import GraphedTrainStep
     model = build_model(device)[0].train()
     step = GraphedTrainStep(model, batch)
@@ -194,7 +195,9 @@ def train_step_line(device, n, w, batch, steps=50):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     return {"batch": batch, "ms_per_step": round(ms, 4), "windows_per_s": round(batch / ms * 1e3, 1),
-            "optimizer": "Adam(fused)", "hip_graph": True, "sensors": n, "window": w}
+            "step_impl": type(step).__name__, "optimizer": "gdn_adam_step (torch.optim.Adam update, flat buffers)"
+            if type(step).__name__ == "NativeTrainStep" else "torch.optim.Adam(fused)",
+            "hip_graph": True, "sensors": n, "window": w}
 
 
 def cpu_baseline(params, budget_s=12.0):
