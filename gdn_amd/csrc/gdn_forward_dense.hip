@@ -176,6 +176,11 @@ struct DArgs {
   const float* out_b;       // [1]
   float* out;               // [B, n]
   const unsigned* plan;     // gdn_fused_plan_build output, or null
+  // optional scoring hand-off: keys[sensor * key_pitch + b] = |out - key_gt| in float64 (the radix keys of
+  // gdn_score_select, evaluate.py:48-50), written by the epilogue instead of a separate transposing kernel
+  const float* key_gt;      // [B, n] ground truth
+  double* keys;             // [n, key_pitch]
+  int key_pitch;
 };
 
 __device__ __forceinline__ float lds_f32(const char* smem, int byte_off) {
@@ -606,6 +611,8 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
     // The image is wave private and LDS executes one wave's accesses in order: scatter the hi term,
     // read it as operands, scatter the lo term over the same positions, read again — no barrier.
     // Operand reads run one k-step ahead of the products (two named fragment sets).
+    float ygt = 0.f;                                  // issued here, consumed after the products
+    if (a.keys && h == 0 && tgt < n) ygt = a.key_gt[(size_t)b * n + tgt];
     f32x16 acc2[DC];
 #pragma unroll
     for (int cb = 0; cb < DC; ++cb)
@@ -681,7 +688,11 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
         }
       }
     part += __shfl_xor(part, 32);
-    if (h == 0 && tgt < n) a.out[(size_t)b * n + tgt] = part + k.out_b;
+    if (h == 0 && tgt < n) {
+      const float o = part + k.out_b;
+      a.out[(size_t)b * n + tgt] = o;
+      if (a.keys) a.keys[(size_t)tgt * a.key_pitch + b] = fabs((double)o - (double)ygt);
+    }
     if (b == (int)blockIdx.x) { GDN_STAMP(9) }
   }
   GDN_STAMP(10)
@@ -1292,14 +1303,17 @@ extern "C" int gdn_fused_plan_build(const float* lin_w, const float* node_terms,
 }
 
 static int fused_with_plan(const void* x, int series_len, int first, const void* plan, int batch, int n, int w,
-                           int d, int k, int bf16_storage, float* out, void* stream) {
+                           int d, int k, int bf16_storage, float* out, void* stream, const float* key_gt = nullptr,
+                           double* keys = nullptr, int key_pitch = 0) {
   if (!x || !plan || !out) return GDN_ERR_ARG;
   if (batch <= 0 || n <= 0) return GDN_ERR_ARG;
+  if (keys && (!key_gt || key_pitch < batch)) return GDN_ERR_ARG;
   if (!gdn_dense_fused_supported(n, w, d, k)) return GDN_ERR_UNSUPPORTED;
   DArgs a = {};
   a.x = x; a.series_len = series_len; a.series_first = first;
   a.batch = batch; a.n = n; a.w = w; a.pitch = gdn_nbr_pitch(k); a.d = d;
   a.out = out; a.plan = reinterpret_cast<const unsigned*>(plan);
+  a.key_gt = key_gt; a.keys = keys; a.key_pitch = key_pitch;
   return fused_dispatch(DOP_LAUNCH, a, bf16_storage, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -1312,5 +1326,21 @@ extern "C" int gdn_forward_fused_series_plan(const float* series, int series_len
                                              int batch, int n, int w, int d, int k, float* out, void* stream) {
   if (series_len <= 0 || first < 0 || (long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;
   return fused_with_plan(series, series_len, first, plan, batch, n, w, d, k, 0, out, stream);
+}
+
+// The same two launches, also leaving the scoring keys |out - gt| (float64, [n, key_pitch], key_pitch >= batch)
+extern "C" int gdn_forward_fused_plan_keys(const void* x, const void* plan, const float* gt, double* keys,
+                                           int key_pitch, int batch, int n, int w, int d, int k, int bf16_storage,
+                                           float* out, void* stream) {
+  if (!gt || !keys) return GDN_ERR_ARG;
+  return fused_with_plan(x, 0, 0, plan, batch, n, w, d, k, bf16_storage, out, stream, gt, keys, key_pitch);
+}
+
+extern "C" int gdn_forward_fused_series_plan_keys(const float* series, int series_len, int first, const void* plan,
+                                                  const float* gt, double* keys, int key_pitch, int batch, int n,
+                                                  int w, int d, int k, float* out, void* stream) {
+  if (!gt || !keys) return GDN_ERR_ARG;
+  if (series_len <= 0 || first < 0 || (long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;
+  return fused_with_plan(series, series_len, first, plan, batch, n, w, d, k, 0, out, stream, gt, keys, key_pitch);
 }
 #endif  // GDN_DENSE_EXTRA_DC

@@ -404,13 +404,18 @@ class SeriesEvaluator:
         self.graph = None
         self.fgraph = None
         self.use_graph = use_graph
+        # GDN_FUSE_KEYS=1: the forward's epilogue writes the scoring keys itself (gdn_forward_fused_plan_keys) and
+        # the gdn_score_keys launch disappears.  Measured SLOWER and therefore off by default: the 127 scattered
+        # 8-byte stores per window (row pitch 256 KB) cost the forward ~40 us per 32768 windows, the transposing
+        # keys kernel 14 us (step 0.379 vs 0.352 ms).
+        self.fuse_keys = os.environ.get("GDN_FUSE_KEYS", "0") == "1"
         # independent batches are launched round-robin on side streams (fork/join around the
         # forward), so consecutive launches overlap each other's ramp-up and tail (two streams measured
         # best at 4096-window launches: 0.634 ms/step vs 0.697 with one and 0.676 with four)
         n_launch = (self.t + self.batch - 1) // self.batch
         self.side = [torch.cuda.Stream(device=dev) for _ in range(min(streams, n_launch))] if streams > 1 else []
 
-    def _launch_forward(self):
+    def _launch_forward(self, with_keys: bool = False):
         m = self.model
         # constants and the plan are built (when stale) HERE, on the caller's stream, before the fork: built
         # lazily inside the first side-stream launch, the launches on the other side streams would read them
@@ -419,12 +424,16 @@ class SeriesEvaluator:
             src = self.series if self.series is not None else self.x
             m._plan(m._constants(), src.dtype == torch.bfloat16)
         spans = [(s, min(self.t, s + self.batch)) for s in range(0, self.t, self.batch)]
+        # scoring hand-off: the forward's epilogue writes the float64 radix keys |pred - y| of its windows into
+        # their columns of the [n, t] key block at the head of the scoring workspace (no gdn_score_keys launch)
+        def keys(s, e):
+            return (self.y[s:e], self.ws.data_ptr() + 8 * s, self.t) if with_keys else None
         if self.series is not None:
             def launch(s, e):
-                m.forward_series(self.series, s, e - s, out=self.pred[s:e])
+                m.forward_series(self.series, s, e - s, out=self.pred[s:e], keys=keys(s, e))
         else:
             def launch(s, e):
-                m.forward_into(self.x[s:e], self.pred[s:e])
+                m.forward_into(self.x[s:e], self.pred[s:e], keys=keys(s, e))
         if len(self.side) < 2:
             for s, e in spans:
                 launch(s, e)
@@ -442,18 +451,24 @@ class SeriesEvaluator:
             join.record(st)
             main.wait_event(join)
 
-    def _launch_score(self):
+    def _launch_score(self, have_keys: bool = False):
         from . import _lib
         st = torch.cuda.current_stream().cuda_stream
-        _lib.call("gdn_score_quantiles", self.pred.data_ptr(), self.y.data_ptr(), self.t, self.n,
-                  self.ws.data_ptr(), self.med_iqr.data_ptr(), st)
+        if have_keys:       # keys [n, t] already sit at the head of the workspace (same layout gdn_score_quantiles uses)
+            _lib.call("gdn_score_select", self.ws.data_ptr(), 1, self.n, self.t, self.t,
+                      self.ws.data_ptr() + 8 * self.t * self.n, self.med_iqr.data_ptr(), st)
+        else:
+            _lib.call("gdn_score_quantiles", self.pred.data_ptr(), self.y.data_ptr(), self.t, self.n,
+                      self.ws.data_ptr(), self.med_iqr.data_ptr(), st)
         _lib.call("gdn_score_smooth_max", self.pred.data_ptr(), self.y.data_ptr(), self.med_iqr.data_ptr(),
                   self.t, self.n, 0, None, None,
                   None if self.scores is None else self.scores.data_ptr(), self.anomaly.data_ptr(), st)
 
     def _launch_all(self):
-        self._launch_forward()
-        self._launch_score()
+        src = self.series if self.series is not None else self.x
+        fuse = self.fuse_keys and self.model.fused_keys_supported(src.dtype == torch.bfloat16)
+        self._launch_forward(with_keys=fuse)
+        self._launch_score(have_keys=fuse)
 
     def _fresh(self):
         """Captured graphs bake in the pointers of the model's folded constants: drop them when a

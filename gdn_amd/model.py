@@ -324,8 +324,10 @@ class GDN(nn.Module):
         self._consts = c
         return c
 
-    def _launch_fused(self, x, c, out):
-        """One ctypes call; every argument except x / out comes from the constants cache."""
+    def _launch_fused(self, x, c, out, keys=None):
+        """One ctypes call; every argument except x / out comes from the constants cache.  `keys` = (gt[B, n]
+        fp32, device pointer of the float64 key rows, row pitch): the launch also leaves the scoring keys
+        |out - gt| (planned matrix-core path only)."""
         if not x.is_cuda:
             raise _lib.GdnHipError(f"input is on {x.device}: gdn_amd needs a HIP device (no CPU fallback)")
         ptrs, n, w, d, k = c.fused_args
@@ -338,7 +340,13 @@ class GDN(nn.Module):
         if c.ready is not None and cur != c.stream and not torch.cuda.is_current_stream_capturing():
             cur.wait_event(c.ready)      # (a capture is preceded by a warm-up + synchronize: nothing to wait for)
         st = cur.cuda_stream
-        if plan is not None:
+        if keys is not None:
+            if plan is None:
+                raise _lib.GdnHipError("scoring keys from the forward launch need the planned matrix-core path")
+            gt, key_ptr, key_pitch = keys
+            _lib.call("gdn_forward_fused_plan_keys", x.data_ptr(), plan.data_ptr(), ops._chk(gt, name="gt").data_ptr(),
+                      key_ptr, key_pitch, b, n, w, d, k, int(bf16), out.data_ptr(), st)
+        elif plan is not None:
             _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, int(bf16),
                       out.data_ptr(), st)
         else:
@@ -454,18 +462,23 @@ class GDN(nn.Module):
             self._ones = None if getattr(dp, "inplace", False) else ones
         return dp(ones).reshape(batch * node_num, d), 1.0
 
-    def forward_into(self, data, out):
+    def forward_into(self, data, out, keys=None):
         """Eval fast path writing into a caller-owned [B, N] slice (no allocation, HIP-graph
-        capturable once `_constants()` is warm): used by harness.SeriesEvaluator."""
+        capturable once `_constants()` is warm): used by harness.SeriesEvaluator.  `keys`: see _launch_fused."""
         if self.training or self.out_layer_num != 1:
             raise RuntimeError("forward_into is the eval / out_layer_num == 1 fast path")
         c = self._constants()
         self.learned_graph = c.graph.topk
         if data.dtype not in (torch.float32, torch.bfloat16):
             data = data.float()
-        return self._launch_fused(data.contiguous(), c, out)
+        return self._launch_fused(data.contiguous(), c, out, keys)
 
-    def forward_series(self, series, first: int, batch: int, out=None):
+    def fused_keys_supported(self, bf16: bool = False) -> bool:
+        """True when the eval forward of this model can leave the scoring keys itself (`keys=` of forward_into /
+        forward_series): out_layer_num == 1 on the planned matrix-core path."""
+        return (not self.training) and self.out_layer_num == 1 and self._plan(self._constants(), bf16) is not None
+
+    def forward_series(self, series, first: int, batch: int, out=None, keys=None):
         """Eval forward of `batch` consecutive stride-1 windows taken directly from the raw series
         [node_num, T] (the layout `TimeDataset` slices, datasets/TimeDataset.py:42-49): window b is
         series[:, first+b : first+b+W] and predicts column first+b+W.  No [T, N, W] tensor exists."""
@@ -482,9 +495,17 @@ class GDN(nn.Module):
             d, w = gnn.lin.weight.shape
             if out is None:
                 out = torch.empty((batch, n), dtype=torch.float32, device=series.device)
+            if keys is not None:
+                gt, key_ptr, key_pitch = keys
+                _lib.call("gdn_forward_fused_series_plan_keys", series.data_ptr(), t_len, first, plan.data_ptr(),
+                          ops._chk(gt, name="gt").data_ptr(), key_ptr, key_pitch, batch, n, w, d, c.graph.k,
+                          out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                return out
             _lib.call("gdn_forward_fused_series_plan", series.data_ptr(), t_len, first, plan.data_ptr(), batch, n, w, d,
                       c.graph.k, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
             return out
+        if keys is not None:
+            raise _lib.GdnHipError("scoring keys from the forward launch need the planned matrix-core path")
         return ops.forward_fused_series(series, first, batch, gnn.lin.weight.shape[1], gnn.lin.weight, c.terms,
                                         c.graph, gnn.bias, self.embedding.weight, c.bn1, c.bn2, lin.weight,
                                         lin.bias, out=out)

@@ -46,7 +46,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 15
+#define GDN_ABI_VERSION 16
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -307,6 +307,21 @@ int gdn_forward_fused_plan(const void* x, const void* plan, int batch, int n, in
                            int bf16_storage, float* out, void* stream);
 int gdn_forward_fused_series_plan(const float* series, int series_len, int first, const void* plan,
                                   int batch, int n, int w, int d, int k, float* out, void* stream);
+
+/* The two planned launches with the scoring hand-off folded into their epilogue: besides out[B, n] they leave
+ * keys[sensor * key_pitch + b] = |out[b][sensor] - gt[b][sensor]| in float64 — the radix keys
+ * gdn_score_select consumes (evaluate.py:48-50, util/data.py:75-82), which gdn_score_keys would otherwise
+ * produce in a launch of its own (transposing 2 x 4 bytes in, 8 bytes out per value).  key_pitch >= batch;
+ * slots batch..key_pitch-1 of every row are left untouched (pre-fill them with the all-ones filler when
+ * key_pitch > batch).  Measured on MI355X: the 127 scattered 8-byte stores per window cost the launch more
+ * (+40 us per 32768 windows) than the separate transposing kernel (14 us); harness.SeriesEvaluator uses
+ * them only on request (GDN_FUSE_KEYS=1).                                                                 */
+int gdn_forward_fused_plan_keys(const void* x, const void* plan, const float* gt, double* keys,
+                                int key_pitch, int batch, int n, int w, int d, int k, int bf16_storage,
+                                float* out, void* stream);
+int gdn_forward_fused_series_plan_keys(const float* series, int series_len, int first, const void* plan,
+                                       const float* gt, double* keys, int key_pitch, int batch, int n,
+                                       int w, int d, int k, float* out, void* stream);
 
 /* ---- bf16 STORAGE variants (BASELINE.json configs[2] / configs[4]) --------------------
  * Same arithmetic as the four forward entry points above with the windowed inputs x, the

@@ -302,3 +302,34 @@ def test_quantile_select_on_adversarial_error_distributions(t, gpu_device):
     for i in range(n):
         med, rng = score_oracle.err_median_and_iqr(pred[:, i].numpy(), gt[:, i].numpy())
         np.testing.assert_array_equal(med_iqr[i].cpu().numpy(), np.array([med, rng]), err_msg=f"sensor {i}")
+
+
+@pytest.mark.parametrize("mode", ["windows", "raw_series", "bf16", "coalesced"])
+def test_scoring_keys_written_by_the_forward_equal_the_keys_kernel(mode, gpu_device):
+    """gdn_forward_fused_plan_keys / _series_plan_keys: the forward's epilogue leaves |pred - y| as float64
+    radix keys (what gdn_score_keys computes in a launch of its own) — same predictions, the same key block bit
+    for bit, the same anomaly scores, for ragged multi-launch series, the raw-series form and bf16 windows."""
+    from gdn_amd import harness, ops
+    from test_gpu_forward_parity import random_params
+    model = random_params(127, 15, 30, 64, seed=8).to(gpu_device).eval()
+    g = torch.Generator().manual_seed(4)
+    t, w = 1500, 15
+    raw = torch.rand((127, t + w), generator=g).to(gpu_device)
+    y = raw[:, w:].t().contiguous()
+    x = raw.unfold(1, w, 1)[:, :t].permute(1, 0, 2).contiguous()          # x[b] = raw[:, b : b+w]
+    kw = dict(batch=256, use_graph=True, coalesce=4 if mode == "coalesced" else 1)
+    def make():
+        if mode == "raw_series":
+            return harness.SeriesEvaluator(model, None, y, series=raw, **kw)
+        return harness.SeriesEvaluator(model, x.bfloat16() if mode == "bf16" else x, y, **kw)
+    fused, plain = make(), make()
+    fused.fuse_keys, plain.fuse_keys = True, False          # (off by default: measured slower, harness.py)
+    assert model.fused_keys_supported(mode == "bf16")
+    a_f, a_p = fused.step().clone(), plain.step().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(fused.pred, plain.pred)
+    keys_f = fused.ws[: 127 * t].view(127, t)
+    assert torch.equal(keys_f, ops.score_keys(fused.pred, y, t))
+    assert torch.equal(keys_f, plain.ws[: 127 * t].view(127, t))
+    assert torch.equal(fused.med_iqr, plain.med_iqr) and torch.equal(a_f, a_p)
+    assert torch.equal(fused.step(), a_f)                                  # replay is idempotent
