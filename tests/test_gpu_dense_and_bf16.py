@@ -309,3 +309,43 @@ def test_outlayer_mlp_on_the_matrix_cores(cfg, gpu_device):
     assert model._constants().mlp is not None                     # the HIP kernel ran, not the library GEMMs
     ref = gdn_oracle.forward(f64_params(p), x.double(), cfg["k"], cfg["layers"], graph=model.learned_graph.cpu())
     np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_matrix_core_kernels_over_random_shapes(gpu_device):
+    """A seeded sweep over the whole shape family of the matrix-core kernels (n 2..127, w 1..32, k 1..min(n, 63),
+    d 64 / 128, batch 1..40): fused forward (planned, fp32 and bf16 storage) and the staged fp32 kernels against
+    the float64 oracle.  Catches tile-edge cases the hand-picked shapes miss (n = 32 m and 32 m - 1, k = n,
+    pitch boundaries 15/16, 31/32, 47/48, w = 16/17)."""
+    from gdn_amd import ops
+    rng = np.random.default_rng(20260)
+    shapes = [(31, 16, 15, 64), (32, 17, 16, 64), (33, 1, 31, 64), (63, 32, 47, 64), (64, 8, 48, 64), (65, 15, 63, 64),
+              (95, 3, 32, 128), (96, 16, 1, 128), (97, 17, 30, 64), (2, 5, 1, 64), (2, 5, 2, 128), (127, 32, 63, 128)]
+    while len(shapes) < 44:
+        n = int(rng.integers(2, 128))
+        shapes.append((n, int(rng.integers(1, 33)), int(rng.integers(1, min(n, 63) + 1)), int(rng.choice([64, 64, 128]))))
+    worst = 0.0
+    for idx, (n, w, k, d) in enumerate(shapes):
+        b = int(rng.integers(1, 41))
+        model = random_params(n, w, k, d, seed=100 + idx)
+        p = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+        model = model.to(gpu_device).eval()
+        x = torch.rand((b, n, w), generator=torch.Generator().manual_seed(idx))
+        with torch.no_grad():
+            out = model(x.to(gpu_device), None)
+            out_b = model(x.bfloat16().to(gpu_device), None)
+        c = model._constants()
+        assert c.plans[False] is not None and c.plans[True] is not None, (n, w, k, d)
+        graph = model.learned_graph.cpu()
+        ref = gdn_oracle.forward(f64_params(p), x.double(), k, graph=graph)
+        err = float((out.cpu().double() - ref["out"]).abs().max())
+        worst = max(worst, err)
+        assert err < 2e-6, (n, w, k, d, b, err)
+        ref_b = gdn_oracle.forward(f64_params(p), x.bfloat16().double(), k, graph=graph, storage="bf16")
+        assert float((out_b.cpu().double() - ref_b["out"]).abs().max()) < 2e-4, (n, w, k, d, b)
+        if d == 64:
+            gnn = model.gnn_layers[0].gnn
+            xlin, s_i, s_j = ops.project_fwd(x.to(gpu_device), gnn.lin.weight, c.terms)
+            z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, b, want_alpha=True)
+            np.testing.assert_allclose(z.cpu().double().numpy(), ref["agg"].numpy(), atol=2e-6, rtol=1e-5, err_msg=str((n, w, k)))
+            np.testing.assert_allclose(alpha.cpu().sum(1).numpy(), 1.0, atol=1e-5)
+    assert worst < 2e-6
