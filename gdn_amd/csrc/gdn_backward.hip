@@ -108,7 +108,9 @@ struct BwdPlan {
 // slots are 164 KB per table): alpha and the lists are read from global memory (L2 resident: one window's
 // worth), d_pi goes through a caller-provided [BN, pitch] workspace (written in pass 1, read in pass 2 by
 // other lanes of the SAME workgroup, a barrier in between).  Same arithmetic, same summation order.
-template <int D, int NT, bool GLB>
+// DX = false: d_xlin is left to gdn_dense_attn_bwd_dx (the matrix-core form of pass 2); this kernel then
+// only sums d_s_j over the reverse lists in its second pass.
+template <int D, int NT, bool GLB, bool DX = true>
 __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     const BwdPlan pl, const float* __restrict__ d_z, const float* __restrict__ xlin,
     const float* __restrict__ alpha, const float* __restrict__ s_i, const float* __restrict__ s_j,
@@ -220,13 +222,13 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
       }
     }
     __syncthreads();
-    {   // the tile now holds d_z of this window (row n stays 0)
+    if constexpr (DX) {   // the tile now holds d_z of this window (row n stays 0)
       const float4* src = reinterpret_cast<const float4*>(d_z + row0 * D);
       float4* dst = reinterpret_cast<float4*>(tile);
 #pragma unroll 4
       for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
+      __syncthreads();
     }
-    __syncthreads();
 
     // ---- pass 2: per source, over its reverse list; the first two rounds of BL sources are fetched together
     for (int jb = slot; jb < pl.n; jb += tpp * BL) {
@@ -255,11 +257,13 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
           const bool valid = e < len;
           const uint32_t ent = r0 == 0 ? e0[q] : (r0 == 16 ? e1[q] : rrow[valid ? e : 0]);
           const int i = valid ? (int)(ent >> 16) : 0, p = valid ? (int)(ent & 0xffff) : 0;
-          const float a = valid ? al_t[i * pl.pitch + p] : 0.f;
           dsj += valid ? dpi_t[i * pl.pitch + p] : 0.f;
-          axpy_steps<D>(tile_lane, a, (valid ? i : pl.n) * (D * 4), acc);
+          if constexpr (DX) {
+            const float a = valid ? al_t[i * pl.pitch + p] : 0.f;
+            axpy_steps<D>(tile_lane, a, (valid ? i : pl.n) * (D * 4), acc);
+          }
         }
-        stp<G::VEC>(d_xlin + (row0 + j) * D + d0, acc);
+        if constexpr (DX) stp<G::VEC>(d_xlin + (row0 + j) * D + d0, acc);
         dsj = row16_sum(dsj);
         if (l16 == 0 && slice == 0) d_sj[row0 + j] = dsj;
       }
@@ -558,14 +562,23 @@ extern "C" long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, in
   return (long long)batch * n * gdn_nbr_pitch(k) * (long long)sizeof(float);
 }
 
+// 1 when gdn_attn_aggregate_bwd[_ws] reads the reverse lists (gdn_graph_reverse) at this shape, 0 when it runs
+// the matrix-core backward, which does not (rent / rlen may then be null and the launch can be skipped)
+extern "C" int gdn_attn_aggregate_bwd_uses_reverse(int n, int d, int k) {
+  static const bool valu_bwd = [] { const char* e = getenv("GDN_BWD_PATH"); return e && e[0] == 'v'; }();
+  if (n <= 0 || k <= 0 || k > n) return 1;
+  return (d == 64 && !valu_bwd && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k)) ? 0 : 1;
+}
+
 extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, const float* alpha,
                                          const float* s_i, const float* s_j, const uint16_t* nbr,
                                          const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
                                          int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
                                          float* workspace, void* stream) {
-  if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !rent || !rlen || !d_xlin || !d_si || !d_sj ||
-      !d_bias || batch <= 0 || n <= 0 || k <= 0)
+  if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !d_xlin || !d_si || !d_sj || !d_bias || batch <= 0 ||
+      n <= 0 || k <= 0)
     return GDN_ERR_ARG;
+  if ((!rent || !rlen) && gdn_attn_aggregate_bwd_uses_reverse(n, d, k)) return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
   BwdPlan pl;
@@ -576,6 +589,11 @@ extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, co
     glb = true;
   }
   hipStream_t st = (hipStream_t)stream;
+  const bool wide = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
+  // matrix-core shapes: both halves of the backward as dense products (gdn_forward_dense.hip).
+  // GDN_BWD_PATH=valu keeps the row-gather kernel below (A/B runs)
+  if (!gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
+    return gdn_dense_attn_bwd(d_z, xlin, alpha, s_i, s_j, nbr, batch, n, k, d_xlin, d_si, d_sj, d_bias, st);
 #define GDN_BWD_NT(DD, NT, GL)                                                                        \
   {                                                                                                   \
     const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD, NT, GL>, NT, pl.lds_bytes, batch);        \
@@ -588,7 +606,6 @@ extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, co
     else if (wide) GDN_BWD_NT(DD, 512, false)                         \
     else GDN_BWD_NT(DD, 256, false)                                   \
     break;
-  const bool wide = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
   switch (d) {
     GDN_BWD(16)
     GDN_BWD(32)

@@ -38,6 +38,9 @@ int gdn_dense_forward_fused(const void* x, int x_is_bf16, int series_len, int se
 int gdn_dense_attn_aggregate(const void* xlin, int is_bf16, const float* s_i, const float* s_j, const uint16_t* nbr,
                              const float* bias, int batch, int n, int d, int k, void* z, float* alpha,
                              hipStream_t stream);
+int gdn_dense_attn_bwd(const float* d_z, const float* xlin, const float* alpha, const float* s_i, const float* s_j,
+                       const uint16_t* nbr, int batch, int n, int k, float* d_xlin, float* d_si, float* d_sj,
+                       float* d_bias, hipStream_t stream);        // matrix-core backward of the gather-aggregate
 int gdn_dense_project(const void* x, int is_bf16, const float* lin_w, const float* node_terms, int batch, int n,
                       int w, int d, void* xlin, float* s_i, float* s_j, hipStream_t stream);
 // run-time choice between the two fused forward implementations: GDN_FUSED_PATH=valu keeps the fp32 VALU

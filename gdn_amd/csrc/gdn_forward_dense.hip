@@ -923,6 +923,397 @@ __global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kern
   }
 }
 
+// ------------------------------------------------------------------ backward of the gather-aggregate
+// Autograd of models/graph_layer.py:106-117 (what gdn_attn_aggregate_bwd computes with row gathers) as two
+// dense matrix-core products per window:
+//   G  = dZ . X^T   [targets x sources, K = 64]   g_iq = G[i][nbr(i,q)] = d_z_i . xlin_j  (d alpha)
+//   dX = A^T . dZ   [sources x 64, K = targets]   the reverse gather
+// and between them, per (target, slot) lane as in the forward's softmax phase:
+//   de = alpha (g - sum_q alpha g),  dl = de * LeakyReLU'(s_i + s_j),  d_s_i = sum_q dl,  d_s_j = column sums.
+// d_z (gradients of a mean loss sit around 1e-6, below the f16 normal range) is scaled per window by a power
+// of two chosen from max|d_z|, exactly, and every output is unscaled by the same power.  The d_z tile is staged
+// as two f16 terms in K8's row-major swizzled layout (the dX product reads it transposed, ds_read_b64_tr_b16,
+// against ONE transposed attention image shared by the workgroup: a wave's 32 output rows are sources, whose
+// weights come from every target; the G product reads its rows as A fragments), the xlin tile directly in
+// operand order (B fragments of G, conflict free).  G goes through LDS once (each wave its own 32 target
+// rows, gathered by the same wave: no barrier); DL takes its place (the wave clears its rows and writes dl where
+// an edge exists) and d_s_j = its column sums in a fixed order: deterministic, no atomics, no reverse lists.
+// d_bias = column sums of d_z.  One workgroup per CU (134 KB of LDS at n = 127).
+struct BwArgs {
+  const float* d_z;        // [BN, 64]
+  const float* xlin;       // [BN, 64]
+  const float* alpha;      // [BN, pitch] (padding slots 0)
+  const float* si;         // [BN]
+  const float* sj;
+  const uint16_t* nbr;     // [n, pitch]
+  int batch, n, pitch;
+  float* d_xlin;           // [BN, 64]
+  float* d_si;             // [BN]
+  float* d_sj;
+  float* d_bias;           // [64], accumulated with atomics (as gdn_attn_aggregate_bwd)
+};
+
+template <int NT, int SL>
+struct BwCfg {
+  static constexpr int KS = 2 * NT;
+  static constexpr int ROWS = 32 * NT;
+  static constexpr int THREADS = 64 * NT;
+  static constexpr int AROW = KS * 32 + 16;
+  static constexpr int AIMG = ROWS * AROW;
+  static constexpr int TPLANE = ROWS * 128;
+  static constexpr int GROW = ROWS * 4;                 // one row of G / DL^T: ROWS fp32
+  static constexpr int GBYTES = ROWS * GROW;
+  static constexpr int OFF_A = 0;
+  static constexpr int OFF_DZ = AIMG;
+  static constexpr int OFF_X = OFF_DZ + 2 * TPLANE;     // the xlin tile, later G, later DL^T
+  static constexpr int OFF_G = OFF_X;
+  static constexpr int GREG = GBYTES > 2 * TPLANE ? GBYTES : 2 * TPLANE;
+  static constexpr int OFF_SI = OFF_G + GREG;
+  static constexpr int OFF_SJ = OFF_SI + ROWS * 4;
+  static constexpr int OFF_MAX = OFF_SJ + ROWS * 4;
+  static constexpr int LDS = OFF_MAX + 16;
+  static constexpr int RSTEP = THREADS / 16;
+  static constexpr int TU = ROWS / RSTEP;               // 16-byte pieces per thread and tile: 8
+};
+
+template <int NT, int SL>
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gdn_dense_attn_bwd_kernel(const BwArgs a) {
+  using C = BwCfg<NT, SL>;
+  using F = Fmt<FMT_F16>;
+  constexpr int DC = 2;
+  extern __shared__ uint4 smem_u4[];
+  char* smem = reinterpret_cast<char*>(smem_u4);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int n = a.n;
+  unsigned* wmax = reinterpret_cast<unsigned*>(smem + C::OFF_MAX);     // [2]: max |d_z| of a window (bits), by parity
+
+  // ---------------------------------------------------------------- once per workgroup
+  for (int t = tid; t < C::AIMG / 16; t += C::THREADS) reinterpret_cast<uint4*>(smem + C::OFF_A)[t] = make_uint4(0, 0, 0, 0);
+  for (int t = tid; t < (2 * C::TPLANE + C::GREG) / 16; t += C::THREADS)       // pad rows of both tiles stay zero
+    reinterpret_cast<uint4*>(smem + C::OFF_DZ)[t] = make_uint4(0, 0, 0, 0);
+  if (tid < 2) wmax[tid] = 0u;
+  const int ti = 32 * wv + (lane >> 1);
+  const int half = lane & 1;
+  int scoff[SL], sjoff[SL], goff[SL];
+  {
+    const uint16_t* row = a.nbr + (size_t)min(ti, n - 1) * a.pitch + half * SL;
+    const int col = pos_of_source(ti) * 2;
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+      const int jj = (int)row[q];
+      const int j = ti < n ? jj : n;                    // row / column n = the sentinel: zeros only
+      scoff[q] = C::OFF_A + j * C::AROW + col;
+      sjoff[q] = C::OFF_SJ + j * 4;
+      goff[q] = C::OFF_G + ti * C::GROW + j * 4;        // G / DL [target ti][source j] (this wave's own rows)
+    }
+  }
+  const int si_off = C::OFF_SI + ti * 4;
+  // tile staging (K8's layout): piece u of this thread = row prow0 + u RSTEP, 16-byte piece ppc of the row
+  const int ppc = tid % 16, prow0 = tid / 16;
+  const int t_st = prow0 * 128 + (((ppc >> 3) ^ ((prow0 >> 1) & 1)) * 64 + (ppc & 7) * 8);
+  const int t_voff = (prow0 * 64 + ppc * 4) * 4;
+  bool tok[C::TU];
+#pragma unroll
+  for (int u = 0; u < C::TU; ++u) tok[u] = prow0 + u * C::RSTEP < n;
+  const size_t t_total = (size_t)a.batch * n * 64 * 4;
+  uint4 pdz[C::TU], px[C::TU];
+  float psi, psj;
+  const int sn = min(tid, n - 1);
+  auto load_window = [&](int bb) {
+    const size_t first = (size_t)bb * n * 64 * 4;
+    const size_t rem = t_total - first;
+    const int lim = (int)(rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.d_z)) + first, 0, lim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.xlin)) + first, 0, lim, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < C::TU; ++u) {
+      pdz[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rz, t_voff, u * (C::RSTEP * 256), 0));
+      px[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, t_voff, u * (C::RSTEP * 256), 0));
+    }
+    psi = a.si[(size_t)bb * n + sn];
+    psj = a.sj[(size_t)bb * n + sn];
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // d_bias: this thread's columns 4 ppc .. 4 ppc + 3
+  load_window(blockIdx.x);
+  __syncthreads();
+  if (tid == 0) *reinterpret_cast<float*>(smem + C::OFF_SJ + n * 4) = 0.f;
+
+  // operand addressing
+  const int rsw = (l32 >> 1) & 1;
+  auto piece = [&](int ks) { return (((ks >> 1) ^ rsw) * 64) + ((32 * ks + 16 * h) & 63); };   // bytes inside a row
+  const int arow_off = C::OFF_A + wv * (32 * C::AROW) + l32 * C::AROW + h * 16;   // image rows 32wv + l32 (sources)
+  const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tsw = (tq >> 1) & 1;
+  const int tr_base = C::OFF_DZ + (4 * h + tq) * 128 + 32 * (g4 & 1) + 8 * tp;
+  using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+
+  GDN_STAMP(20)
+  int par = 0;
+  for (int b = blockIdx.x; b < a.batch; b += gridDim.x, par ^= 1) {
+    // ---- attention weights of this lane's slots (issued first: consumed several barriers later)
+    float al[SL];
+    {
+      const float4* src = reinterpret_cast<const float4*>(a.alpha + ((size_t)b * n + min(ti, n - 1)) * a.pitch + half * SL);
+#pragma unroll
+      for (int q = 0; q < SL; q += 4) {
+        const float4 v = src[q / 4];
+        al[q] = v.x; al[q + 1] = v.y; al[q + 2] = v.z; al[q + 3] = v.w;
+      }
+      if (ti >= n) {
+#pragma unroll
+        for (int q = 0; q < SL; ++q) al[q] = 0.f;
+      }
+    }
+if (b == (int)blockIdx.x) { GDN_STAMP(21) }
+        // ---- scale of the window (2^kexp, max|d_z| 2^kexp in [2^12, 2^13)) and the d_bias partial sums
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < C::TU; ++u) {
+      if (!tok[u]) continue;
+      const float v0 = __uint_as_float(pdz[u].x), v1 = __uint_as_float(pdz[u].y);
+      const float v2 = __uint_as_float(pdz[u].z), v3 = __uint_as_float(pdz[u].w);
+      bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) mx = fmaxf(mx, __shfl_xor(mx, dd));
+    if (lane == 0) atomicMax(&wmax[par], __float_as_uint(mx));   // non-negative floats order like their bits
+    __syncthreads();                                             // B0 (also: previous window fully retired)
+if (b == (int)blockIdx.x) { GDN_STAMP(22) }
+        const unsigned mbits = wmax[par];
+    if (tid == 0) wmax[par ^ 1] = 0u;                            // the next window's slot
+    int kexp = 12 - ((int)((mbits >> 23) & 255u) - 127);
+    kexp = mbits == 0u ? 0 : max(-100, min(100, kexp));
+    const float scale = __uint_as_float((unsigned)(kexp + 127) << 23);
+    const float unscale = __uint_as_float((unsigned)(127 - kexp) << 23);
+#pragma unroll
+    for (int u = 0; u < C::TU; ++u) {
+      if (!tok[u]) continue;
+      {
+        char* dst = smem + C::OFF_DZ + t_st + u * (C::RSTEP * 128);
+        const float v0 = __uint_as_float(pdz[u].x) * scale, v1 = __uint_as_float(pdz[u].y) * scale;
+        const float v2 = __uint_as_float(pdz[u].z) * scale, v3 = __uint_as_float(pdz[u].w) * scale;
+        const unsigned h0 = F::pk(v0, v1), h1 = F::pk(v2, v3);
+        const unsigned l0 = F::pk(F::res0(h0, v0), F::res1(h0, v1)), l1 = F::pk(F::res0(h1, v2), F::res1(h1, v3));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + C::TPLANE) = make_uint2(l0, l1);
+      }
+    }
+    // the xlin tile in OPERAND order — [k-step][source tile][term][lane] x 16 bytes, what the G product reads as
+    // its B fragments with consecutive lanes on consecutive banks (read as rows of the swizzled row-major
+    // layout the same fragments are 8-way bank conflicts); rows >= n are written as zeros every window (the
+    // region held G / DL of the previous one)
+#pragma unroll
+    for (int u = 0; u < C::TU; ++u) {
+      const int row = prow0 + u * C::RSTEP;
+      char* dst = smem + C::OFF_X + ((((ppc >> 2) * NT + (row >> 5)) * 2) * 64 + (row & 31) + 32 * ((ppc & 3) >> 1)) * 16 +
+                  8 * (ppc & 1);
+      unsigned h0 = 0u, h1 = 0u, l0 = 0u, l1 = 0u;
+      if (tok[u]) {
+        const float v0 = __uint_as_float(px[u].x), v1 = __uint_as_float(px[u].y);
+        const float v2 = __uint_as_float(px[u].z), v3 = __uint_as_float(px[u].w);
+        h0 = F::pk(v0, v1); h1 = F::pk(v2, v3);
+        l0 = F::pk(F::res0(h0, v0), F::res1(h0, v1)); l1 = F::pk(F::res0(h1, v2), F::res1(h1, v3));
+      }
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(l0, l1);
+    }
+    if (tid < n) {
+      *reinterpret_cast<float*>(smem + C::OFF_SI + tid * 4) = psi;
+      *reinterpret_cast<float*>(smem + C::OFF_SJ + tid * 4) = psj;
+    }
+    if (tid == n) *reinterpret_cast<float*>(smem + C::OFF_SJ + n * 4) = 0.f;   // the sentinel (d_s_j partials reuse this array)
+    __syncthreads();                                             // B1: tiles + scalars ready
+if (b == (int)blockIdx.x) { GDN_STAMP(23) }
+        load_window(min(b + (int)gridDim.x, a.batch - 1));
+
+    // ---- G = dZ . X^T : A = d_z rows of this wave's targets, B = xlin rows (sources) of column tile tn
+    f32x16 accg[NT];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accg[tn][r] = 0.f;
+    {
+      u32x4 fdz[2][2], fxx[2][NT][2];                 // [buffer][..][hi, lo]
+      auto fetch_g = [&](int ks, int buf) {
+        const int po = piece(ks);
+        fdz[buf][0] = lds_frag(smem, C::OFF_DZ + (32 * wv + l32) * 128 + po);
+        fdz[buf][1] = lds_frag(smem, C::OFF_DZ + C::TPLANE + (32 * wv + l32) * 128 + po);
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          fxx[buf][tn][0] = lds_frag(smem, C::OFF_X + (((ks * NT + tn) * 2) * 64 + lane) * 16);
+          fxx[buf][tn][1] = lds_frag(smem, C::OFF_X + (((ks * NT + tn) * 2 + 1) * 64 + lane) * 16);
+        }
+      };
+      fetch_g(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) fetch_g(ks + 1, (ks + 1) & 1);   // lands under this k-step's products
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          accg[tn] = F::mfma(fdz[ks & 1][0], fxx[ks & 1][tn][0], accg[tn]);
+          accg[tn] = F::mfma(fdz[ks & 1][1], fxx[ks & 1][tn][0], accg[tn]);
+          accg[tn] = F::mfma(fdz[ks & 1][0], fxx[ks & 1][tn][1], accg[tn]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+if (b == (int)blockIdx.x) { GDN_STAMP(24) }
+        __syncthreads();                                             // B2: every wave is done with the xlin tile
+    // G rows of this wave -> its own block of the G region (register r = target 32wv + (r&3) + 8(r>>2) + 4h)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
+        *reinterpret_cast<float*>(smem + C::OFF_G + row * C::GROW + (32 * tn + l32) * 4) = accg[tn][r];
+      }
+if (b == (int)blockIdx.x) { GDN_STAMP(25) }
+        // ---- softmax backward per (target, slot): in-order LDS within the wave, no barrier needed for its own rows
+    float dl[SL];
+    {
+      const float sti = lds_f32(smem, si_off);
+      float g[SL], sjv[SL];
+#pragma unroll
+      for (int q = 0; q < SL; ++q) {
+        g[q] = lds_f32(smem, goff[q]);
+        sjv[q] = lds_f32(smem, sjoff[q]);
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < SL; ++q) dot = fmaf(al[q], g[q], dot);
+      dot += dpp_f<GDN_DPP_XOR1>(dot);
+      float dsi = 0.f;
+#pragma unroll
+      for (int q = 0; q < SL; ++q) {
+        const float de = al[q] * (g[q] - dot);
+        dl[q] = de * ((sti + sjv[q]) > 0.f ? 1.f : GDN_NEG_SLOPE);
+        dsi += dl[q];
+      }
+      dsi += dpp_f<GDN_DPP_XOR1>(dsi);
+      if (half == 0 && ti < n) a.d_si[(size_t)b * n + ti] = dsi * unscale;
+    }
+if (b == (int)blockIdx.x) { GDN_STAMP(26) }
+    // DL[target][source] takes the place of G: the wave clears its own 32 rows (its gathers are done: LDS is
+    // in order within a wave) and writes dl where an edge exists — no barrier, no workgroup-wide zero fill
+    for (int t = lane; t < 32 * C::GROW / 16; t += 64)
+      reinterpret_cast<uint4*>(smem + C::OFF_G + 32 * wv * C::GROW)[t] = make_uint4(0, 0, 0, 0);
+if (b == (int)blockIdx.x) { GDN_STAMP(27) }
+#pragma unroll
+    for (int q = 0; q < SL; ++q) *reinterpret_cast<float*>(smem + goff[q]) = dl[q];    // (padding slots: column n, value 0)
+    // the two 16-bit terms of the weights; hi terms into the shared transposed image
+    unsigned ph[SL / 2], pl[SL / 2];
+#pragma unroll
+    for (int q = 0; q < SL; q += 2) {
+      const float a0 = al[q] * GDN_F16_ALPHA_SCALE, a1 = al[q + 1] * GDN_F16_ALPHA_SCALE;
+      ph[q / 2] = F::pk(a0, a1);
+      pl[q / 2] = F::pk(F::res0(ph[q / 2], a0), F::res1(ph[q / 2], a1));
+    }
+    scatter_terms<SL>(smem, scoff, ph);
+    __syncthreads();                                             // B5: DL^T and the hi image complete
+if (b == (int)blockIdx.x) { GDN_STAMP(28) }
+        // d_s_j = column sums of DL: lane = column (a wave's reads fall on consecutive banks), two threads per
+    // source (even / odd targets), fixed order; the halves meet after the next barrier
+    float* dsj_part = reinterpret_cast<float*>(smem + C::OFF_SI);       // [2][ROWS]: s_i / s_j are dead by now
+    if (tid < 2 * C::ROWS || C::THREADS < 2 * C::ROWS) {
+      for (int cc = tid; cc < 2 * C::ROWS; cc += C::THREADS) {
+        const int j = cc % C::ROWS, hf = cc / C::ROWS;
+        const char* colp = smem + C::OFF_G + hf * C::GROW + j * 4;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < C::ROWS / 2; t += 4) {
+          s0 += lds_f32(colp, (t + 0) * 2 * C::GROW);
+          s1 += lds_f32(colp, (t + 1) * 2 * C::GROW);
+          s2 += lds_f32(colp, (t + 2) * 2 * C::GROW);
+          s3 += lds_f32(colp, (t + 3) * 2 * C::GROW);
+        }
+        dsj_part[cc] = (s0 + s1) + (s2 + s3);
+      }
+    }
+if (b == (int)blockIdx.x) { GDN_STAMP(29) }
+        // ---- dX = A^T . dZ
+    f32x16 acc[DC];
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    u32x4 fa[2], fx[2][DC][2];
+    auto fetch = [&](int ks, int buf, int nterms) {
+      fa[buf] = lds_frag(smem, arow_off + ks * 32);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t >= nterms) continue;
+          const char* p0 = smem + tr_base + t * C::TPLANE + ks * 2048;
+          const int co = cb == 0 ? tsw * 64 : (tsw ^ 1) * 64;
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + co));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + co + 1024));
+          const uint2 u0 = __builtin_bit_cast(uint2, r0), u1 = __builtin_bit_cast(uint2, r1);
+          fx[buf][cb][t] = u32x4{u0.x, u0.y, u1.x, u1.y};
+        }
+    };
+    fetch(0, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) fetch(ks + 1, (ks + 1) & 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[cb] = F::mfma(fa[ks & 1], fx[ks & 1][cb][t], acc[cb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+if (b == (int)blockIdx.x) { GDN_STAMP(30) }
+        __syncthreads();                                             // B6: every wave is done with the hi image
+    if (tid < n) a.d_sj[(size_t)b * n + tid] = (dsj_part[tid] + dsj_part[C::ROWS + tid]) * unscale;
+    scatter_terms<SL>(smem, scoff, pl);
+    __syncthreads();                                             // B7: lo image complete
+    fetch(0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) fetch(ks + 1, (ks + 1) & 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < DC; ++cb) acc[cb] = F::mfma(fa[ks & 1], fx[ks & 1][cb][0], acc[cb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+if (b == (int)blockIdx.x) { GDN_STAMP(31) }
+        // ---- d_xlin rows: register r = source 32wv + (r&3) + 8(r>>2) + 4h, lane = column
+    const float un2 = unscale * (1.f / GDN_F16_ALPHA_SCALE);
+#pragma unroll
+    for (int cb = 0; cb < DC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < n) a.d_xlin[((size_t)b * n + row) * 64 + cb * 32 + l32] = acc[cb][r] * un2;
+      }
+    if (b == (int)blockIdx.x) { GDN_STAMP(32) }
+    // (the next iteration's B0 orders these reads of the image / tiles before they are rewritten)
+  }
+  GDN_STAMP(33)
+  // ---- d_bias: column sums over this workgroup's windows (16 row groups per column piece)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem + C::OFF_G);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) red[(tid / 16) * 64 + ppc * 4 + v] = bsum[v];
+  __syncthreads();
+  if (tid < 64) {
+    float t = 0.f;
+    for (int r = 0; r < C::THREADS / 16; ++r) t += red[r * 64 + tid];
+    atomicAdd(&a.d_bias[tid], t);
+  }
+  GDN_STAMP(34)
+}
+
 // ------------------------------------------------------------------ staged projection
 // xlin[b] = x[b] . lin^T (models/graph_layer.py:56) and the attention scalars s_i, s_j of every sensor
 // (graph_layer.py:94-104 folded: s = x_row . a + c[sensor]) on the 16-bit matrix cores: the P phase of
@@ -1226,6 +1617,42 @@ int gdn_dense_project(const void* x, int is_bf16, const float* lin_w, const floa
     case 2: return is_bf16 ? launch_project<2, FMT_BF16>(a, stream) : launch_project<2, FMT_F16>(a, stream);
     case 3: return is_bf16 ? launch_project<3, FMT_BF16>(a, stream) : launch_project<3, FMT_F16>(a, stream);
     case 4: return is_bf16 ? launch_project<4, FMT_BF16>(a, stream) : launch_project<4, FMT_F16>(a, stream);
+  }
+  return GDN_ERR_UNSUPPORTED;
+}
+
+template <int NT, int SL>
+static int launch_attn_bwd(const BwArgs& a, hipStream_t stream) {
+  using C = BwCfg<NT, SL>;
+  static_assert(C::LDS <= 160 * 1024, "LDS plan exceeds one CU");
+  auto kern = gdn_dense_attn_bwd_kernel<NT, SL>;
+  const int occ = blocks_per_cu(reinterpret_cast<const void*>(kern), C::THREADS, C::LDS);
+  const int grid = max(1, min(a.batch, cu_count() * occ));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
+  return gdn_launch_status();
+}
+
+template <int NT>
+static int attn_bwd_select_sl(const BwArgs& a, hipStream_t st) {
+  switch (a.pitch) {
+    case 16: return launch_attn_bwd<NT, 8>(a, st);
+    case 32: return launch_attn_bwd<NT, 16>(a, st);
+    case 48: return launch_attn_bwd<NT, 24>(a, st);
+    case 64: return launch_attn_bwd<NT, 32>(a, st);
+  }
+  return GDN_ERR_UNSUPPORTED;
+}
+
+int gdn_dense_attn_bwd(const float* d_z, const float* xlin, const float* alpha, const float* s_i, const float* s_j,
+                       const uint16_t* nbr, int batch, int n, int k, float* d_xlin, float* d_si, float* d_sj,
+                       float* d_bias, hipStream_t stream) {
+  if (!gdn_dense_supported(n, 1, 64, k)) return GDN_ERR_UNSUPPORTED;
+  BwArgs a = {d_z, xlin, alpha, s_i, s_j, nbr, batch, n, gdn_nbr_pitch(k), d_xlin, d_si, d_sj, d_bias};
+  switch ((n + 1 + 31) / 32) {
+    case 1: return attn_bwd_select_sl<1>(a, stream);
+    case 2: return attn_bwd_select_sl<2>(a, stream);
+    case 3: return attn_bwd_select_sl<3>(a, stream);
+    case 4: return attn_bwd_select_sl<4>(a, stream);
   }
   return GDN_ERR_UNSUPPORTED;
 }

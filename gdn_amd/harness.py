@@ -783,6 +783,7 @@ class NativeTrainStep:
                 act=torch.empty((bn_rows, d), **f32), d_act=torch.empty((bn_rows, d), **f32),
                 mlp_saved=torch.empty((lib.gdn_mlp_train_saved_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev),
                 mlp_ws=torch.empty((lib.gdn_mlp_train_workspace_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev))
+        self._need_reverse = bool(lib.gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self._fork = os.environ.get("GDN_TRAIN_FORK", "0") == "1"
         self.use_graph = use_graph
@@ -838,7 +839,8 @@ class NativeTrainStep:
             # graph rows and folded terms in one launch (independent work, one launch less on the critical path)
             call("gdn_topk_graph_terms", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], P(g + "lin.weight"),
                  P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"), w, pt["terms"], st)
-            call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], st)
+            if self._need_reverse:       # only the row-gather backward reads the reverse lists
+                call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], st)
             call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
                  pt["s_j"], st)
         call("gdn_attn_aggregate_fwd", pt["xlin"], pt["s_i"], pt["s_j"], pt["nbr"], pt["deg"], P(g + "bias"), b, n, d, k,

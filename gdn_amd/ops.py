@@ -438,7 +438,8 @@ def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: in
     d_si = torch.empty((bn,), dtype=torch.float32, device=d_z.device)
     d_sj = torch.empty_like(d_si)
     d_bias = torch.zeros((d,), dtype=torch.float32, device=d_z.device)
-    rent, rlen = graph.reverse()
+    # the matrix-core backward (n <= 127, d = 64) does not read the reverse lists: they are not even built then
+    rent, rlen = graph.reverse() if _lib.load().gdn_attn_aggregate_bwd_uses_reverse(n, d, graph.k) else (None, None)
     nbytes = _lib.load().gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, graph.k)     # > 0: tables beyond LDS
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=d_z.device) if nbytes else None
     _lib.call("gdn_attn_aggregate_bwd_ws", _ptr(d_z), _ptr(_chk(xlin)), _ptr(_chk(alpha)), _ptr(_chk(s_i)),

@@ -46,7 +46,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 16
+#define GDN_ABI_VERSION 17
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -375,6 +375,12 @@ int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alp
                            const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
                            int batch, int n, int d, int k,
                            float* d_xlin, float* d_si, float* d_sj, float* d_bias, void* stream);
+
+/* Shapes on the matrix-core path (n <= 127, d = 64, k <= 63) run the backward as two dense products per
+ * window (G = dZ . X^T for d alpha, dX = A^T . dZ for the reverse gather; d_z scaled per window by a power of
+ * two, every factor as two f16 terms) and do not read the reverse lists: gdn_attn_aggregate_bwd_uses_reverse
+ * returns 0 there, rent / rlen may be null and gdn_graph_reverse need not run.                         */
+int gdn_attn_aggregate_bwd_uses_reverse(int n, int d, int k);
 
 /* Large sensor counts: when the tile plus the two [n, pitch] tables exceed LDS (n ~> 250 at d = 64,
  * k = 30; the 512-sensor / k = 64 stress shape), the tables go through global memory and d_pi through a
