@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -41,6 +41,8 @@ SIGNATURES = {
     "gdn_forward_fused_plan_keys": [_p] * 4 + [_c_int] * 7 + [_p, _p],
     "gdn_forward_fused_series_plan_keys": [_p, _c_int, _c_int] + [_p] * 3 + [_c_int] * 6 + [_p, _p],
     "gdn_attn_aggregate_bwd_uses_reverse": [_c_int] * 3,
+    "gdn_head_mse_workspace_bytes": [],
+    "gdn_head_train_fwd_rng_mse": [_p] * 9 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 12 + [_c_int, _p],
     "gdn_adam_step": [_p] * 5 + [_c_int] + [ctypes.c_double] * 6 + [_c_int, _c_int, _p],
     "gdn_terms_bwd_acc": [_p] * 8 + [_c_int] * 3 + [_p] * 6 + [_c_int, _p],
     "gdn_mse_workspace_bytes": [],

@@ -62,6 +62,13 @@ struct HeadArgs {
   double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
   float* demb_part;      // backward: [EMB_PARTS][n][d] per-part sums of d_emb
   float *out, *d_z;
+  // forward, fused loss (train.py:20-23 F.mse_loss + the first step of loss.backward()): when y is given the
+  // last forward pass also writes d_out = 2 (out - y) / count and reduces the loss (per-workgroup fp64 partials,
+  // the last workgroup to finish adds them in a fixed order: gdn_mse_kernel's scheme, one launch less)
+  const float* y;        // [BN]
+  float* mse_d_out;      // [BN]
+  double* mse_ws;        // [1 + grid]: ticket, partials
+  float* loss;           // [1]
   float* act;            // forward, MLP head (out_layer_num > 1): the [BN, d] activation after dropout instead of `out`
   const float* d_act;    // backward, MLP head: its gradient instead of d_out (x) lin.weight
   int batch, n;
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
   double acc_s = 0.0;
   const float bias_o = (MODE == H_OUT && a.bo) ? a.bo[0] : 0.f;
+  const float mse_scale = (float)(2.0 / rows);
   if (live) {
     for (int bq = b0; bq < b1; bq += U) {
       load_round(bq);
@@ -282,7 +290,15 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
           for (int v = 0; v < 4; ++v) part_o = fmaf(a2[v] * m[v], w4[v], part_o);
 #pragma unroll
           for (int s = 1; s < G::LPR; s <<= 1) part_o += __shfl_xor(part_o, s);   // lanes of one row
-          if (lr == 0) a.out[row] = part_o + bias_o;
+          if (lr == 0) {
+            const float o = part_o + bias_o;
+            a.out[row] = o;
+            if (a.y) {
+              const float df = o - a.y[row];
+              acc_s = fma((double)df, (double)df, acc_s);
+              a.mse_d_out[row] = df * mse_scale;
+            }
+          }
           continue;
         }
         const float go = goq[u];
@@ -331,6 +347,44 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
     }
   }
 
+  if constexpr (MODE == H_OUT) {
+    if (a.y) {                                    // loss = mean((out - y)^2): fixed-order reduction, last workgroup finishes
+      __shared__ bool last;
+      __syncthreads();
+      red[tid] = acc_s;
+      __syncthreads();
+      for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) red[tid] += red[tid + q];
+        __syncthreads();
+      }
+      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.mse_ws);
+      if (tid == 0) {
+        // no release/acquire fence (each would write back this XCD's whole L2: ~20 us over 512 workgroups): the
+        // partial is an agent-scope atomic store, acknowledged (vmcnt) before the ticket is taken, and the last
+        // workgroup reads the partials back with agent-scope atomic loads
+        __hip_atomic_store(a.mse_ws + 1 + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == (unsigned long long)gridDim.x - 1ull;
+      }
+      __syncthreads();
+      if (last) {
+        double sum = 0.0;
+        for (int q = tid; q < (int)gridDim.x; q += 256)
+          sum += __hip_atomic_load(a.mse_ws + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[tid] = sum;
+        __syncthreads();
+        for (int q = 128; q > 0; q >>= 1) {
+          if (tid < q) red[tid] += red[tid + q];
+          __syncthreads();
+        }
+        if (tid == 0) {
+          a.loss[0] = (float)(red[0] / rows);
+          __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
   const int repl = blockIdx.x % GDN_HEAD_REPL;
   if constexpr (MODE == H_STAT1 || MODE == H_STAT2) {
     double* dst = a.acc + (size_t)repl * 4 * D + (MODE == H_STAT1 ? 0 : 2 * D);
@@ -497,7 +551,9 @@ static int head_train_fwd_impl(const float* z, const float* emb, const float* bn
                                   float eps2, float momentum1, float momentum2, float* running_mean1,
                                   float* running_var1, long long* batches1, float* running_mean2,
                                   float* running_var2, long long* batches2, double* stats, float* out,
-                                  void* stream, float* act = nullptr, bool zeroed = false) {
+                                  void* stream, float* act = nullptr, bool zeroed = false,
+                                  const float* y = nullptr, float* d_out = nullptr, double* mse_ws = nullptr,
+                                  float* loss = nullptr) {
   if (!z || !emb || !bn1_w || !bn1_b || !bn2_w || !bn2_b || !stats) return GDN_ERR_ARG;
   if (act ? (lin_w || lin_b || out) : (!lin_w || !lin_b || !out)) return GDN_ERR_ARG;
   if (!head_shape_ok(batch, n, d)) return GDN_ERR_ARG;   // torch: "Expected more than 1 value per channel"
@@ -510,6 +566,7 @@ static int head_train_fwd_impl(const float* z, const float* emb, const float* bn
     a.rng = rng; a.rng_threshold = drop_threshold(p_drop); a.keep_scale = 1.f / (1.f - p_drop);
   }
   a.fstats = stats; a.acc = stats; a.out = out; a.act = act; a.batch = batch; a.n = n;
+  a.y = y; a.mse_d_out = d_out; a.mse_ws = mse_ws; a.loss = loss;
   a.eps1 = eps1; a.eps2 = eps2;
   a.run = {running_mean1, running_var1, running_mean2, running_var2, batches1, batches2, momentum1, momentum2};
   if (!zeroed && hipMemsetAsync(stats, 0, (size_t)GDN_HEAD_REPL * 4 * d * sizeof(double), st) != hipSuccess)
@@ -615,6 +672,27 @@ extern "C" int gdn_head_train_bwd(const float* d_out, const float* z, const floa
   return head_train_bwd_impl(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, mask, keep, keep_scale, nullptr, 0.f,
                              stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b, d_bn2_w,
                              d_bn2_b, d_lin_w, d_lin_b, stream);
+}
+
+// gdn_head_train_fwd_rng + gdn_mse_loss_grad in the same launches: the last forward pass also writes
+// d_out = 2 (out - y) / (batch n) and loss[0] = mean((out - y)^2).  mse_workspace: gdn_head_mse_workspace_bytes(),
+// zero-filled once (the ticket is handed back at 0).
+extern "C" long long gdn_head_mse_workspace_bytes(void) { return (4096 + 1) * (long long)sizeof(double); }
+
+extern "C" int gdn_head_train_fwd_rng_mse(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                                          const float* bn2_w, const float* bn2_b, const float* lin_w,
+                                          const float* lin_b, const long long* rng_seed_step, float p_drop,
+                                          int batch, int n, int d, float eps1, float eps2, float momentum1,
+                                          float momentum2, float* running_mean1, float* running_var1,
+                                          long long* batches1, float* running_mean2, float* running_var2,
+                                          long long* batches2, double* stats, float* out, const float* y,
+                                          double* mse_workspace, float* loss, float* d_out, int buffers_zeroed,
+                                          void* stream) {
+  if (!rng_seed_step || p_drop < 0.f || p_drop >= 1.f || !y || !mse_workspace || !loss || !d_out) return GDN_ERR_ARG;
+  return head_train_fwd_impl(z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, lin_b, nullptr, nullptr, 1.f, rng_seed_step,
+                             p_drop, batch, n, d, eps1, eps2, momentum1, momentum2, running_mean1, running_var1,
+                             batches1, running_mean2, running_var2, batches2, stats, out, stream, nullptr,
+                             buffers_zeroed != 0, y, d_out, mse_workspace, loss);
 }
 
 extern "C" int gdn_head_train_bwd_rng(const float* d_out, const float* z, const float* emb, const float* bn1_w,

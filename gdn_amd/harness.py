@@ -773,6 +773,7 @@ class NativeTrainStep:
             proj_ws=torch.empty((lib.gdn_project_bwd_workspace_bytes(n, w, d) // 4,), **f32),
             d_a=torch.empty((128,), **f32), d_c=torch.empty((2 * n,), **f32),
             mse_ws=ops.mse_workspace(dev),
+            head_mse_ws=torch.zeros((lib.gdn_head_mse_workspace_bytes() // 8,), dtype=torch.float64, device=dev),
         )
         self._mlp = None
         if model.out_layer_num > 1:
@@ -786,6 +787,10 @@ class NativeTrainStep:
         self._need_reverse = bool(lib.gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self._fork = os.environ.get("GDN_TRAIN_FORK", "0") == "1"
+        # GDN_FUSE_MSE=1: loss + d_out from the head's last forward pass (gdn_head_train_fwd_rng_mse) instead of
+        # the gdn_mse_loss_grad launch — measured SLOWER (0.198 vs 0.193 ms: 512 workgroups each pay the block
+        # reductions and the ticket), so off by default
+        self._fuse_mse = os.environ.get("GDN_FUSE_MSE", "0") == "1"
         self.use_graph = use_graph
         self._graphs = None
         self._split = world()[1] > 1 if split is None else bool(split)
@@ -853,8 +858,13 @@ class NativeTrainStep:
         run = (m1, m2, rm1, rv1, nb1, rm2, rv2, nb2)
         if self._mlp is None:
             lw, lb = "out_layer.mlp.0.weight", "out_layer.mlp.0.bias"
-            call("gdn_head_train_fwd_rng", pt["z"], P("embedding.weight"), *bnp, P(lw), P(lb), rng, p_drop, b, n, d,
-                 *eps, *run, pt["stats"], pt["out"], 1, st)
+            if self._fuse_mse:   # the loss and its gradient come out of the head's last forward pass
+                call("gdn_head_train_fwd_rng_mse", pt["z"], P("embedding.weight"), *bnp, P(lw), P(lb), rng, p_drop, b, n, d,
+                     *eps, *run, pt["stats"], pt["out"], self.y.data_ptr(), pt["head_mse_ws"], self.loss.data_ptr(),
+                     pt["d_out"], 1, st)
+            else:
+                call("gdn_head_train_fwd_rng", pt["z"], P("embedding.weight"), *bnp, P(lw), P(lb), rng, p_drop, b, n, d,
+                     *eps, *run, pt["stats"], pt["out"], 1, st)
         else:
             # out_layer_num > 1: head passes up to the dropped-out activation, then the MLP on the matrix cores
             h, layers, bns = self._mlp
@@ -870,7 +880,8 @@ class NativeTrainStep:
                  (ctypes.c_float * len(bns))(*[float(bn.eps) for bn in bns]),
                  (ctypes.c_float * len(bns))(*[r[0] for r in runs]), P(lw), P(lb), b * n, d, h, layers,
                  pt["mlp_saved"], pt["mlp_ws"], pt["out"], st)
-        call("gdn_mse_loss_grad", pt["out"], self.y.data_ptr(), b * n, pt["mse_ws"], self.loss.data_ptr(), pt["d_out"], st)
+        if self._mlp is not None or not self._fuse_mse:
+            call("gdn_mse_loss_grad", pt["out"], self.y.data_ptr(), b * n, pt["mse_ws"], self.loss.data_ptr(), pt["d_out"], st)
         # backward: gradients land in their slots of flat_g
         if self._mlp is None:
             call("gdn_head_train_bwd_rng", pt["d_out"], pt["z"], P("embedding.weight"), *bnp, P(lw), rng, p_drop,

@@ -46,7 +46,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 17
+#define GDN_ABI_VERSION 18
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -196,6 +196,22 @@ int gdn_head_train_bwd_rng(const float* d_out, const float* z, const float* emb,
                            double* workspace, float* d_z, float* d_emb, float* d_bn1_w, float* d_bn1_b,
                            float* d_bn2_w, float* d_bn2_b, float* d_lin_w, float* d_lin_b,
                            int buffers_zeroed, void* stream);
+/* gdn_head_train_fwd_rng with the loss folded in (train.py:20-23,70-72: F.mse_loss + the first step of
+ * loss.backward()): the last forward pass also writes d_out = 2 (out - y) / (batch n) and loss[0] =
+ * mean((out - y)^2) — per-workgroup fp64 partials added in a fixed order by the last workgroup to finish, as
+ * gdn_mse_loss_grad does, without its launch.  mse_workspace: gdn_head_mse_workspace_bytes(), zero-filled once.
+ * (Measured on MI355X at 512 windows: 5 us slower than the separate launch — every one of the 512 workgroups
+ * pays the block reduction and the ticket; harness.NativeTrainStep uses it only with GDN_FUSE_MSE=1.)        */
+long long gdn_head_mse_workspace_bytes(void);
+int gdn_head_train_fwd_rng_mse(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
+                               const float* bn2_w, const float* bn2_b, const float* lin_w,
+                               const float* lin_b, const long long* rng_seed_step, float p_drop,
+                               int batch, int n, int d, float eps1, float eps2, float momentum1,
+                               float momentum2, float* running_mean1, float* running_var1,
+                               long long* batches1, float* running_mean2, float* running_var2,
+                               long long* batches2, double* stats, float* out, const float* y,
+                               double* mse_workspace, float* loss, float* d_out, int buffers_zeroed,
+                               void* stream);
 /* buffers_zeroed (the _rng and _act entry points): 0 = the call zero-fills its accumulators itself (a
  * memset launch each in forward and backward); 1 = the caller guarantees `stats` (forward) / the first
  * gdn_head_train_stats_bytes-style block of `workspace` (backward) are zero on entry, and the backward
