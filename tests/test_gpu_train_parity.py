@@ -699,3 +699,75 @@ def test_native_step_variants_agree(gpu_device, monkeypatch):
     keep = torch.ones_like(results[0][1], dtype=torch.bool)
     keep[off:off + cnt] = False
     np.testing.assert_allclose(results[0][1][keep].cpu().numpy(), results[1][1][keep].cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_matrix_core_backward_of_the_aggregate_over_random_shapes(gpu_device):
+    """gdn_attn_aggregate_bwd on the matrix-core path (n <= 127, d = 64: G = dZ.X^T and dX = A^T.dZ as dense
+    products, d_z scaled per window) against float64 autograd of the same layer (graph_layer.py:106-117 in list
+    form), over a seeded sweep of shapes and with the gradient magnitude varying by 12 orders of magnitude
+    BETWEEN the windows of one launch (the per-window power-of-two scaling)."""
+    from gdn_amd import _lib, ops
+    rng = np.random.default_rng(7)
+    shapes = [(127, 30), (127, 63), (2, 1), (31, 15), (32, 16), (33, 31), (64, 47), (65, 48), (96, 5), (97, 32)]
+    while len(shapes) < 22:
+        n = int(rng.integers(2, 128))
+        shapes.append((n, int(rng.integers(1, min(n, 63) + 1))))
+    for idx, (n, k) in enumerate(shapes):
+        b, d = int(rng.integers(1, 12)), 64
+        assert _lib.load().gdn_attn_aggregate_bwd_uses_reverse(n, d, k) == 0          # the dense path takes it
+        g = torch.Generator().manual_seed(idx)
+        emb = torch.randn((n, d), generator=g)
+        graph = ops.topk_graph(emb.to(gpu_device), k)
+        xlin = torch.randn((b * n, d), generator=g)
+        s_i, s_j = torch.randn((b * n,), generator=g), torch.randn((b * n,), generator=g)
+        bias = torch.randn((d,), generator=g) * 0.1
+        mags = 10.0 ** torch.from_numpy(rng.uniform(-9, 3, size=b)).float()          # per-window gradient scale
+        d_z = (torch.randn((b, n, d), generator=g) * mags.view(b, 1, 1)).reshape(b * n, d)
+        dev = lambda t: t.to(gpu_device)
+        z, alpha = ops.attn_aggregate_fwd(dev(xlin), dev(s_i), dev(s_j), graph, dev(bias), b, want_alpha=True)
+        d_xlin, d_si, d_sj, d_bias = ops.attn_aggregate_bwd(dev(d_z), dev(xlin), alpha, dev(s_i), dev(s_j), graph, b)
+        # float64 autograd of the layer in list form
+        nbr = graph.nbr.cpu().long()                                       # [n, pitch], padding = n
+        x64 = xlin.double().view(b, n, d).requires_grad_(True)
+        si64 = s_i.double().view(b, n).requires_grad_(True)
+        sj64 = s_j.double().view(b, n).requires_grad_(True)
+        b64 = bias.double().requires_grad_(True)
+        xpad = torch.cat((x64, torch.zeros((b, 1, d), dtype=torch.float64)), 1)
+        sjpad = torch.cat((sj64, torch.full((b, 1), -float("inf"), dtype=torch.float64)), 1)
+        e = torch.nn.functional.leaky_relu(si64.unsqueeze(-1) + sjpad[:, nbr], 0.2)
+        a64 = torch.softmax(e, dim=-1)
+        z64 = (a64.unsqueeze(-1) * xpad[:, nbr]).sum(2) + b64
+        np.testing.assert_allclose(z.cpu().double().numpy(), z64.detach().reshape(b * n, d).numpy(), atol=3e-6, rtol=1e-5)
+        z64.backward(d_z.double().view(b, n, d))
+        scale = mags.double().view(b, 1, 1)                                 # compare per window, relative to its scale
+        for name, got, want in (("d_xlin", d_xlin.view(b, n, d), x64.grad), ("d_si", d_si.view(b, n, 1), si64.grad.unsqueeze(-1)),
+                                ("d_sj", d_sj.view(b, n, 1), sj64.grad.unsqueeze(-1))):
+            err = ((got.cpu().double() - want) / scale).abs().max()
+            ref = (want / scale).abs().max().clamp_min(1.0)
+            assert float(err / ref) < 3e-6, (n, k, b, name, float(err / ref))
+        np.testing.assert_allclose(d_bias.cpu().double().numpy(), b64.grad.numpy(), rtol=2e-5,
+                                   atol=2e-6 * float(mags.max()) * (b * n) ** 0.5)
+
+
+def test_graph_and_terms_single_launch_equals_the_two_entry_points(gpu_device):
+    """gdn_topk_graph_terms (one launch, used by the native training step) against gdn_topk_graph + gdn_node_terms:
+    identical graph tables and folded attention terms, bit for bit."""
+    from gdn_amd import _lib, ops
+    for n, k, d, w in ((127, 30, 64, 15), (27, 5, 64, 5), (512, 64, 128, 30), (40, 16, 128, 30)):
+        g = torch.Generator().manual_seed(n)
+        emb = torch.randn((n, d), generator=g).to(gpu_device)
+        lin_w = torch.randn((d, w), generator=g).to(gpu_device)
+        att = [torch.randn((d,), generator=g).to(gpu_device) for _ in range(4)]
+        graph = ops.topk_graph(emb, k)
+        terms = ops.node_terms(lin_w, *[t.view(1, 1, d) for t in att], emb)
+        pitch = ops.nbr_pitch(k)
+        topk = torch.empty((n, k), dtype=torch.int64, device=gpu_device)
+        nbr = torch.empty((n, pitch), dtype=torch.uint16, device=gpu_device)
+        deg = torch.empty((n,), dtype=torch.int32, device=gpu_device)
+        terms2 = torch.empty_like(terms)
+        _lib.call("gdn_topk_graph_terms", emb.data_ptr(), n, d, k, topk.data_ptr(), nbr.data_ptr(), deg.data_ptr(),
+                  lin_w.data_ptr(), *[t.data_ptr() for t in att], w, terms2.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(topk, graph.topk) and torch.equal(deg, graph.deg)
+        assert torch.equal(nbr.view(torch.int16), graph.nbr.view(torch.int16))
+        assert torch.equal(terms2, terms)
