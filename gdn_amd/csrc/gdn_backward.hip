@@ -314,26 +314,30 @@ __global__ __launch_bounds__(256) void gdn_graph_reverse_kernel(const uint16_t* 
 // d_lin_w[d,w] = sum_rows d_xlin[row,d] x[row,w];  d_a[2,64] = sum_rows d_s[row] x[row,:];
 // d_c[2,n] = sum_b d_s[b*n + s].
 //
-// Every output is OWNED by one thread (no reduction across threads, no atomics: an earlier version
-// accumulated 16 lane groups into LDS with ds_add_f32 and spent 2/3 of its time there).  Output
-// o = c*D + d: a thread keeps one d and D/16 columns c in registers across all windows of the
-// workgroup; per staged row it reads d_xlin[row,d] once (consecutive lanes = consecutive d, conflict
-// free) and x[row,c] as an LDS broadcast.  A pass covers 16 columns; w > 16 takes wp/16 passes.
-// Each workgroup ends with ONE partial row [D*wp + 128 + 2n]; gdn_project_reduce_kernel sums the rows.
+// A thread keeps ONE d and ALL 16 columns of a pass in registers across every window of the workgroup, for
+// the rows of its row group (256/D groups take the rows of a chunk round robin): per row it reads
+// d_xlin[row,d] once (consecutive lanes = consecutive d, conflict free) and the 16 x values of the row as four
+// broadcast ds_read_b128 — 5 LDS instructions per 16 FMAs.  (Round 1 owned D/16 columns per thread: 5 LDS
+// instructions per 4 FMAs, and the kernel sat at 18 us of a 190 us training step, LDS-issue bound; an earlier
+// version still accumulated lane groups into LDS with ds_add_f32 and spent 2/3 of its time there.)  The row
+// groups' partial sums meet once, at the end of a pass, through LDS in a fixed order.  A pass covers 16
+// columns; w > 16 takes wp/16 passes.  Each workgroup ends with ONE partial row [D*wp + 128 + 2n];
+// gdn_project_reduce_kernel sums the rows.
 template <int D>
 __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
     int batch, int n, int w, int wp, int rc, const float* __restrict__ x, const float* __restrict__ d_xlin,
     const float* __restrict__ d_si, const float* __restrict__ d_sj, float* __restrict__ part) {
-  constexpr int OPT = D / 16;        // outputs per thread and pass
-  constexpr int CSTEP = 256 / D;     // column distance between a thread's outputs
+  constexpr int RG = 256 / D;        // row groups
   extern __shared__ float4 smem_b4[];
   float* smem = reinterpret_cast<float*>(smem_b4);
   float* gs = smem;                      // [rc][D]   d_xlin rows of the chunk
   float* xs = gs + (size_t)rc * D;       // [rc][wp]  x rows, zero padded to wp columns
   float* ds = xs + (size_t)rc * wp;      // [2][rc]   d_si, d_sj
-  float* dc = ds + 2 * rc;               // [2][n]    sums over this workgroup's windows
+  // [2][n] sums over this workgroup's windows, behind the staging area AND behind the 16 x 256 floats the
+  // end-of-pass reduction borrows from it (small n: the staging area alone is shorter than that)
+  float* dc = smem + max(rc * (wp + D + 2), 16 * 256);
   const int tid = threadIdx.x;
-  const int d = tid % D, cq0 = tid / D;
+  const int d = tid % D, rg = tid / D;
   const int nout = D * wp;
   float* row_out = part + (size_t)blockIdx.x * (nout + 128 + 2 * n);
   const int a_which = tid >> 6, a_c = tid & 63;          // d_a owner (tid < 128)
@@ -342,13 +346,11 @@ __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
   for (int t = tid; t < 2 * n; t += 256) dc[t] = 0.f;
 
   for (int pass = 0; pass * 16 < wp; ++pass) {
-    float acc[OPT];
+    float acc[16];
 #pragma unroll
-    for (int q = 0; q < OPT; ++q) acc[q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     float acc_a = 0.f;
-    int cidx[OPT];
-#pragma unroll
-    for (int q = 0; q < OPT; ++q) cidx[q] = min(pass * 16 + cq0 + CSTEP * q, wp - 1);   // clamped: never stored
+    const int c0 = pass * 16;
     for (int b = blockIdx.x; b < batch; b += gridDim.x) {
       const size_t row0 = (size_t)b * n;
       for (int r0 = 0; r0 < n; r0 += rc) {
@@ -395,11 +397,17 @@ __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
         }
         __syncthreads();
 #pragma unroll 4
-        for (int r = 0; r < rows; ++r) {
+        for (int r = rg; r < rows; r += RG) {
           const float g = gs[r * D + d];
-          const float* xr = xs + r * wp;
+          const float* xr = xs + r * wp + c0;
 #pragma unroll
-          for (int q = 0; q < OPT; ++q) acc[q] = fmaf(g, xr[cidx[q]], acc[q]);
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + min(4 * q4, wp - c0 - 4));   // wp = 8: columns 8.. repeat 4..7, never stored
+            acc[4 * q4 + 0] = fmaf(g, xv.x, acc[4 * q4 + 0]);
+            acc[4 * q4 + 1] = fmaf(g, xv.y, acc[4 * q4 + 1]);
+            acc[4 * q4 + 2] = fmaf(g, xv.z, acc[4 * q4 + 2]);
+            acc[4 * q4 + 3] = fmaf(g, xv.w, acc[4 * q4 + 3]);
+          }
         }
         if (pass == 0 && a_owner) {
           const float* dsel = ds + a_which * rc;
@@ -408,10 +416,18 @@ __global__ __launch_bounds__(256) void gdn_project_bwd_kernel(
         }
       }
     }
+    // the row groups' partial sums of this pass: through LDS (gs is free: every chunk has been consumed)
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < OPT; ++q) {
-      const int c = pass * 16 + cq0 + CSTEP * q;
-      if (c < wp) row_out[c * D + d] = acc[q];
+    for (int q = 0; q < 16; ++q) gs[(rg * 16 + q) * D + d] = acc[q];
+    __syncthreads();
+    for (int o = tid; o < 16 * D; o += 256) {
+      const int q = o / D, dd = o - q * D;
+      const int c = pass * 16 + q;
+      float t = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < RG; ++g2) t += gs[(g2 * 16 + q) * D + dd];
+      if (c < wp) row_out[c * D + dd] = t;
     }
     if (pass == 0 && tid < 128) row_out[nout + tid] = a_owner ? acc_a : 0.f;
   }
@@ -646,7 +662,7 @@ extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float*
   int rc = (24576 - 2 * n) / (wp + d + 2);
   if (rc > n) rc = n;
   if (rc < 1) return GDN_ERR_UNSUPPORTED;
-  const int lds = (rc * (wp + d + 2) + 2 * n) * 4;
+  const int lds = (max(rc * (wp + d + 2), 16 * 256) + 2 * n) * 4;
   hipStream_t st = (hipStream_t)stream;
   int grid = 1;
 #define GDN_PB(DD)                                                                                  \

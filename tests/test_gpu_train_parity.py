@@ -540,8 +540,12 @@ def test_native_train_step_equals_the_autograd_step(p_drop, layers, gpu_device):
         assert float(diff.max()) <= 6e-3, name                          # never more than the 5 steps of size lr
         if not noise_only:
             # everything else within 2e-5 — except that single ELEMENTS whose gradient happens to sit at the rounding
-            # level behave like the noise-only parameters (seen once in a run of this test): at most 0.5 % of a tensor
-            assert float((diff > 2e-5).float().mean()) <= 5e-3, (name, float(diff.max()))
+            # level behave like the noise-only parameters: Adam's step is lr * m / sqrt(v) whatever the gradient's size,
+            # so an element with |g| ~ 1e-8 (the run-to-run noise of the fp64 / fp32 atomics in the statistics and
+            # bias reductions) moves by +-lr in a direction that differs between two correct runs.  Seen in ~1 of 3
+            # runs of the 3-layer case, always well under 1 % of a weight matrix: at most 2 % of a tensor may do so.
+            # (The first step's gradients are compared element by element above, at 2e-6.)
+            assert float((diff > 2e-5).float().mean()) <= 2e-2, (name, float(diff.max()))
     if p_drop > 0:
         kept = torch.stack(masks).ne(0).float().mean().item()
         assert abs(kept - (1.0 - p_drop)) < 2e-3         # the draw has the right rate
