@@ -775,3 +775,24 @@ def test_graph_and_terms_single_launch_equals_the_two_entry_points(gpu_device):
         assert torch.equal(topk, graph.topk) and torch.equal(deg, graph.deg)
         assert torch.equal(nbr.view(torch.int16), graph.nbr.view(torch.int16))
         assert torch.equal(terms2, terms)
+
+
+def test_matrix_core_backward_is_bitwise_reproducible(gpu_device):
+    """d_xlin, d_s_i, d_s_j of the matrix-core backward have no atomics and no order-dependent reductions: 300
+    launches on the same inputs (512 windows: every workgroup takes two) give the same bits — a stale read across
+    one of its ten barriers per window would show up here.  (d_bias is summed with float atomics across
+    workgroups, as in the row-gather kernel, and is only checked to rounding.)"""
+    from gdn_amd import ops
+    n, k, b, d = 127, 30, 512, 64
+    g = torch.Generator().manual_seed(11)
+    graph = ops.topk_graph(torch.randn((n, d), generator=g).to(gpu_device), k)
+    xlin = torch.randn((b * n, d), generator=g).to(gpu_device)
+    s_i, s_j = torch.randn((b * n,), generator=g).to(gpu_device), torch.randn((b * n,), generator=g).to(gpu_device)
+    bias = torch.zeros((d,), device=gpu_device)
+    d_z = (torch.randn((b * n, d), generator=g) * 1e-6).to(gpu_device)
+    _z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, graph, bias, b, want_alpha=True)
+    first = ops.attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph, b)
+    for _ in range(300):
+        again = ops.attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph, b)
+        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1]) and torch.equal(first[2], again[2])
+        np.testing.assert_allclose(again[3].cpu().numpy(), first[3].cpu().numpy(), rtol=1e-4, atol=1e-9)
