@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -43,6 +43,8 @@ SIGNATURES = {
     "gdn_attn_aggregate_bwd_uses_reverse": [_c_int] * 3,
     "gdn_head_mse_workspace_bytes": [],
     "gdn_head_train_fwd_rng_mse": [_p] * 9 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 12 + [_c_int, _p],
+    "gdn_project_bwd_partials": [_p] * 4 + [_c_int] * 4 + [_p, _p, _p],
+    "gdn_train_finish": [_p, _p] + [_c_int] * 4 + [_p] * 8 + [_c_int, _c_int] + [_p] * 4,
     "gdn_adam_step": [_p] * 5 + [_c_int] + [ctypes.c_double] * 6 + [_c_int, _c_int, _p],
     "gdn_terms_bwd_acc": [_p] * 8 + [_c_int] * 3 + [_p] * 6 + [_c_int, _p],
     "gdn_mse_workspace_bytes": [],

@@ -443,35 +443,7 @@ __global__ __launch_bounds__(256) void gdn_project_reduce_kernel(const float* __
                                                                  float* __restrict__ d_lin_w,
                                                                  float* __restrict__ d_a,
                                                                  float* __restrict__ d_c) {
-  __shared__ float red[16][17];
-  const int len = d * wp + 128 + 2 * n;
-  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int t = blockIdx.x * 16 + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (t < len) {
-    int r = g;
-    for (; r + 48 < rows; r += 64) {
-      s0 += part[(size_t)r * len + t];
-      s1 += part[(size_t)(r + 16) * len + t];
-      s2 += part[(size_t)(r + 32) * len + t];
-      s3 += part[(size_t)(r + 48) * len + t];
-    }
-    for (; r < rows; r += 16) s0 += part[(size_t)r * len + t];
-  }
-  red[g][c] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (g != 0 || t >= len) return;
-  float s = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) s += red[q][c];
-  if (t < d * wp) {
-    const int cc = t / d, r = t - cc * d;     // partial rows hold d_lin_w column-major (c*D + d)
-    if (cc < w) d_lin_w[(size_t)r * w + cc] = s;
-  } else if (t < d * wp + 128) {
-    d_a[t - d * wp] = s;
-  } else {
-    d_c[t - d * wp - 128] = s;
-  }
+  gdn_project_reduce_body(part, rows, d, n, w, wp, d_lin_w, d_a, d_c, (int)blockIdx.x);
 }
 
 // Chain rule through the folded constants a = lin^T att (node_terms) and c = emb . att_em:
@@ -648,16 +620,14 @@ extern "C" long long gdn_project_bwd_workspace_bytes(int n, int w, int d) {
   return (long long)GDN_PBWD_MAX_ROWS * (d * wp + 128 + 2 * n) * (long long)sizeof(float);
 }
 
-extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
-                               int batch, int n, int w, int d, float* workspace, float* d_lin_w, float* d_a,
-                               float* d_c, void* stream) {
-  if (!x || !d_xlin || !d_si || !d_sj || !workspace || !d_lin_w || !d_a || !d_c || batch <= 0 || n <= 0 ||
-      w <= 0)
-    return GDN_ERR_ARG;
+// first half of gdn_project_bwd: the per-workgroup partial rows; *rows_out = how many there are
+extern "C" int gdn_project_bwd_partials(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
+                                        int batch, int n, int w, int d, float* workspace, int* rows_out,
+                                        void* stream) {
+  if (!x || !d_xlin || !d_si || !d_sj || !workspace || !rows_out || batch <= 0 || n <= 0 || w <= 0) return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (w > GDN_MAX_W || n > 4096) return GDN_ERR_UNSUPPORTED;
   const int wp = w <= 8 ? 8 : ((w + 15) & ~15);
-  const int len = d * wp + 128 + 2 * n;
   // rows per staged chunk: whole window when it fits ~96 KB (three workgroups per CU at the SWaT shape)
   int rc = (24576 - 2 * n) / (wp + d + 2);
   if (rc > n) rc = n;
@@ -678,8 +648,21 @@ extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float*
     GDN_PB(128)
   }
 #undef GDN_PB
-  hipLaunchKernelGGL(gdn_project_reduce_kernel, dim3((len + 15) / 16), dim3(256), 0, st, workspace, grid, d, n,
-                     w, wp, d_lin_w, d_a, d_c);
+  *rows_out = grid;
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_project_bwd(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
+                               int batch, int n, int w, int d, float* workspace, float* d_lin_w, float* d_a,
+                               float* d_c, void* stream) {
+  if (!d_lin_w || !d_a || !d_c) return GDN_ERR_ARG;
+  int rows = 0;
+  const int rc = gdn_project_bwd_partials(x, d_xlin, d_si, d_sj, batch, n, w, d, workspace, &rows, stream);
+  if (rc != GDN_OK) return rc;
+  const int wp = w <= 8 ? 8 : ((w + 15) & ~15);
+  const int len = d * wp + 128 + 2 * n;
+  hipLaunchKernelGGL(gdn_project_reduce_kernel, dim3((len + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace,
+                     rows, d, n, w, wp, d_lin_w, d_a, d_c);
   return gdn_launch_status();
 }
 

@@ -101,3 +101,41 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
 }
+
+// Sum of the per-workgroup partial rows of gdn_project_bwd ([rows][D*wp + 128 + 2n] -> d_lin_w[D,w], d_a[2,64],
+// d_c[2,n]): workgroup `block` sums 16 columns — 16 lane groups take every 16th row (four independent chains
+// each, so the loads overlap), then an LDS reduce.  A device function because two kernels run it: the plain
+// reduce launch and the training step's combined tail launch (gdn_head_train.hip).
+__device__ __forceinline__ void gdn_project_reduce_body(const float* __restrict__ part, int rows, int d, int n, int w,
+                                                        int wp, float* __restrict__ d_lin_w, float* __restrict__ d_a,
+                                                        float* __restrict__ d_c, int block) {
+  __shared__ float red[16][17];
+  const int len = d * wp + 128 + 2 * n;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = block * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (t < len) {
+    int r = g;
+    for (; r + 48 < rows; r += 64) {
+      s0 += part[(size_t)r * len + t];
+      s1 += part[(size_t)(r + 16) * len + t];
+      s2 += part[(size_t)(r + 32) * len + t];
+      s3 += part[(size_t)(r + 48) * len + t];
+    }
+    for (; r < rows; r += 16) s0 += part[(size_t)r * len + t];
+  }
+  red[g][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0 || t >= len) return;
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += red[q][c];
+  if (t < d * wp) {
+    const int cc = t / d, r = t - cc * d;     // partial rows hold d_lin_w column-major (c*D + d)
+    if (cc < w) d_lin_w[(size_t)r * w + cc] = s;
+  } else if (t < d * wp + 128) {
+    d_a[t - d * wp] = s;
+  } else {
+    d_c[t - d * wp - 128] = s;
+  }
+}

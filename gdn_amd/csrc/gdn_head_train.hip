@@ -415,11 +415,11 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   }
 }
 
-__global__ void gdn_head_finish_kernel(double* __restrict__ ws, const float* __restrict__ demb_part,
-                                       int parts, int n, int d, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
-                                       float* d_bn2_b, float* d_lin_w, float* d_lin_b, float* d_emb,
-                                       double* zero_stats) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void head_finish_body(double* __restrict__ ws, const float* __restrict__ demb_part,
+                                                 int parts, int n, int d, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
+                                                 float* d_bn2_b, float* d_lin_w, float* d_lin_b, float* d_emb,
+                                                 double* zero_stats, int block) {
+  const int t = block * (int)blockDim.x + (int)threadIdx.x;
   if (t < d && zero_stats) {
     // last reader of both accumulator blocks (every pass of this step is complete): leave them zeroed for the
     // next step, which then needs no memset launches.  Only the thread that reads a column clears it.
@@ -443,6 +443,33 @@ __global__ void gdn_head_finish_kernel(double* __restrict__ ws, const float* __r
     for (int p = 0; p < parts; ++p) s += (double)demb_part[(size_t)p * n * d + t];
     d_emb[t] = (float)s;
   }
+}
+
+__global__ void gdn_head_finish_kernel(double* __restrict__ ws, const float* __restrict__ demb_part,
+                                       int parts, int n, int d, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
+                                       float* d_bn2_b, float* d_lin_w, float* d_lin_b, float* d_emb,
+                                       double* zero_stats) {
+  head_finish_body(ws, demb_part, parts, n, d, d_bn1_w, d_bn1_b, d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, d_emb, zero_stats,
+                   (int)blockIdx.x);
+}
+
+// The training step's two small reductions in ONE launch (a launch costs ~5 us inside a replayed step whatever
+// it does): workgroups [0, g1) finish the head backward (gdn_head_finish_kernel), the rest sum the partial rows
+// of gdn_project_bwd (gdn_project_reduce_kernel).  Independent work, disjoint outputs.
+struct TailArgs {
+  double* head_ws; const float* demb_part; int parts, n, d;
+  float *d_bn1_w, *d_bn1_b, *d_bn2_w, *d_bn2_b, *d_lin_w, *d_lin_b, *d_emb;
+  double* zero_stats;
+  int g1;
+  const float* proj_part; int rows, w, wp;
+  float *d_proj_w, *d_a, *d_c;
+};
+__global__ __launch_bounds__(256) void gdn_train_tail_kernel(const TailArgs t) {
+  if ((int)blockIdx.x < t.g1)
+    head_finish_body(t.head_ws, t.demb_part, t.parts, t.n, t.d, t.d_bn1_w, t.d_bn1_b, t.d_bn2_w, t.d_bn2_b, t.d_lin_w,
+                     t.d_lin_b, t.d_emb, t.zero_stats, (int)blockIdx.x);
+  else
+    gdn_project_reduce_body(t.proj_part, t.rows, t.d, t.n, t.w, t.wp, t.d_proj_w, t.d_a, t.d_c, (int)blockIdx.x - t.g1);
 }
 
 int head_parts(int batch, int chunks, int mode) {
@@ -622,7 +649,7 @@ static int head_train_bwd_impl(const float* d_out, const float* z, const float* 
                                   int n, int d, float eps1, float eps2, double* workspace, float* d_z,
                                   float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w,
                                   float* d_bn2_b, float* d_lin_w, float* d_lin_b, void* stream,
-                                  const float* d_act = nullptr, bool zeroed = false) {
+                                  const float* d_act = nullptr, bool zeroed = false, bool defer_finish = false) {
   if (!z || !emb || !bn1_w || !bn1_b || !bn2_w || !bn2_b || !stats || !workspace ||
       !d_z || !d_emb || !d_bn1_w || !d_bn1_b || !d_bn2_w || !d_bn2_b)
     return GDN_ERR_ARG;
@@ -654,6 +681,7 @@ static int head_train_bwd_impl(const float* d_out, const float* z, const float* 
     GDN_HEAD_B(128)
   }
 #undef GDN_HEAD_B
+  if (defer_finish) return gdn_launch_status();     // the caller runs gdn_train_finish after its project backward
   const int total = n * d > d ? n * d : d;
   const int chunks = (n + 256 / (d / 4) - 1) / (256 / (d / 4));
   hipLaunchKernelGGL(gdn_head_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace,
@@ -705,7 +733,8 @@ extern "C" int gdn_head_train_bwd_rng(const float* d_out, const float* z, const 
   if (!rng_seed_step || p_drop < 0.f || p_drop >= 1.f) return GDN_ERR_ARG;
   return head_train_bwd_impl(d_out, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, lin_w, nullptr, nullptr, 1.f, rng_seed_step,
                              p_drop, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w, d_bn1_b,
-                             d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, stream, nullptr, buffers_zeroed != 0);
+                             d_bn2_w, d_bn2_b, d_lin_w, d_lin_b, stream, nullptr, (buffers_zeroed & 1) != 0,
+                             (buffers_zeroed & 2) != 0);
 }
 
 // MLP head (out_layer_num > 1, models/GDN.py:27-56): the same passes, ending at the [BN, d] activation
@@ -736,6 +765,36 @@ extern "C" int gdn_head_train_bwd_act(const float* d_act, const float* z, const 
   return head_train_bwd_impl(nullptr, z, emb, bn1_w, bn1_b, bn2_w, bn2_b, nullptr, mask, keep, keep_scale,
                              rng_seed_step, p_drop, stats, batch, n, d, eps1, eps2, workspace, d_z, d_emb, d_bn1_w,
                              d_bn1_b, d_bn2_w, d_bn2_b, nullptr, nullptr, stream, d_act, buffers_zeroed != 0);
+}
+
+// gdn_head_train_bwd_rng called with buffers_zeroed | 2 leaves out its finishing launch; gdn_project_bwd_partials
+// leaves out the reduce launch; this runs both in one (see gdn_train_tail_kernel).  head_workspace / stats /
+// gradient pointers: as passed to gdn_head_train_bwd_rng; proj_workspace / proj_rows: from
+// gdn_project_bwd_partials.  stats is cleared together with the workspace sums when head_zeroed != 0.
+extern "C" int gdn_train_finish(double* head_workspace, double* stats, int head_zeroed, int batch, int n, int d,
+                                float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w, float* d_bn2_b,
+                                float* d_lin_w, float* d_lin_b, const float* proj_workspace, int proj_rows, int w,
+                                float* d_proj_w, float* d_a, float* d_c, void* stream) {
+  if (!head_workspace || !stats || !d_emb || !d_bn1_w || !d_bn1_b || !d_bn2_w || !d_bn2_b || !d_lin_w || !d_lin_b ||
+      !proj_workspace || !d_proj_w || !d_a || !d_c || batch <= 0 || n <= 0 || w <= 0 || proj_rows <= 0)
+    return GDN_ERR_ARG;
+  if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
+  TailArgs t = {};
+  const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
+  const int chunks = (n + 256 / (d / 4) - 1) / (256 / (d / 4));
+  const int total = n * d > d ? n * d : d;
+  t.head_ws = head_workspace;
+  t.demb_part = reinterpret_cast<const float*>(reinterpret_cast<const char*>(head_workspace) + sums_bytes);
+  t.parts = head_parts(batch, chunks, H_BWD1); t.n = n; t.d = d;
+  t.d_bn1_w = d_bn1_w; t.d_bn1_b = d_bn1_b; t.d_bn2_w = d_bn2_w; t.d_bn2_b = d_bn2_b;
+  t.d_lin_w = d_lin_w; t.d_lin_b = d_lin_b; t.d_emb = d_emb;
+  t.zero_stats = head_zeroed ? stats : nullptr;
+  t.g1 = (total + 255) / 256;
+  t.w = w; t.wp = w <= 8 ? 8 : ((w + 15) & ~15);
+  t.proj_part = proj_workspace; t.rows = proj_rows; t.d_proj_w = d_proj_w; t.d_a = d_a; t.d_c = d_c;
+  const int len = d * t.wp + 128 + 2 * n;
+  hipLaunchKernelGGL(gdn_train_tail_kernel, dim3(t.g1 + (len + 15) / 16), dim3(256), 0, (hipStream_t)stream, t);
+  return gdn_launch_status();
 }
 
 // ---- Adam over ONE flat parameter buffer (reference train.py:31,73: torch.optim.Adam(lr, weight_decay)) ----

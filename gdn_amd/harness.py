@@ -884,8 +884,9 @@ class NativeTrainStep:
             call("gdn_mse_loss_grad", pt["out"], self.y.data_ptr(), b * n, pt["mse_ws"], self.loss.data_ptr(), pt["d_out"], st)
         # backward: gradients land in their slots of flat_g
         if self._mlp is None:
+            # (buffers_zeroed | 2: the head's small finishing reduction runs in the combined tail launch below)
             call("gdn_head_train_bwd_rng", pt["d_out"], pt["z"], P("embedding.weight"), *bnp, P(lw), rng, p_drop,
-                 pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, G(lw), G(lb), 1, st)
+                 pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, G(lw), G(lb), 3, st)
         else:
             call("gdn_mlp_train_bwd", pt["d_out"], pt["act"], arr([P(nm) for nm in names]), P(lw), b * n, d, h, layers,
                  pt["mlp_saved"], pt["mlp_ws"], arr([G(nm) for nm in names]), G(lw), G(lb), pt["d_act"], st)
@@ -894,8 +895,16 @@ class NativeTrainStep:
         main.wait_stream(side2)                      # reverse lists
         call("gdn_attn_aggregate_bwd", pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
              pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), st)     # slot cleared by Adam
-        call("gdn_project_bwd", self.x.data_ptr(), pt["d_xlin"], pt["d_si"], pt["d_sj"], b, n, w, d, pt["proj_ws"],
-             G(g + "lin.weight"), pt["d_a"], pt["d_c"], st)
+        if self._mlp is None:
+            # partial rows only; their reduction and the head's finishing reduction share ONE launch
+            rows = ctypes.c_int(0)
+            call("gdn_project_bwd_partials", self.x.data_ptr(), pt["d_xlin"], pt["d_si"], pt["d_sj"], b, n, w, d,
+                 pt["proj_ws"], ctypes.byref(rows), st)
+            call("gdn_train_finish", pt["head_ws"], pt["stats"], 1, b, n, d, G("embedding.weight"), *bng, G(lw), G(lb),
+                 pt["proj_ws"], rows.value, w, G(g + "lin.weight"), pt["d_a"], pt["d_c"], st)
+        else:
+            call("gdn_project_bwd", self.x.data_ptr(), pt["d_xlin"], pt["d_si"], pt["d_sj"], b, n, w, d, pt["proj_ws"],
+                 G(g + "lin.weight"), pt["d_a"], pt["d_c"], st)
         call("gdn_terms_bwd_acc", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
              P("embedding.weight"), pt["d_a"], pt["d_c"], n, d, w, G(g + "lin.weight"), G(g + "att_i"), G(g + "att_j"),
              G(g + "att_em_i"), G(g + "att_em_j"), G("embedding.weight"), 1, st)

@@ -46,7 +46,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 18
+#define GDN_ABI_VERSION 19
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -212,7 +212,7 @@ int gdn_head_train_fwd_rng_mse(const float* z, const float* emb, const float* bn
                                long long* batches2, double* stats, float* out, const float* y,
                                double* mse_workspace, float* loss, float* d_out, int buffers_zeroed,
                                void* stream);
-/* buffers_zeroed (the _rng and _act entry points): 0 = the call zero-fills its accumulators itself (a
+/* buffers_zeroed (the _rng and _act entry points; bit 1 of gdn_head_train_bwd_rng's: see gdn_train_finish): 0 = the call zero-fills its accumulators itself (a
  * memset launch each in forward and backward); 1 = the caller guarantees `stats` (forward) / the first
  * gdn_head_train_stats_bytes-style block of `workspace` (backward) are zero on entry, and the backward
  * leaves BOTH zeroed again when it finishes — a training loop that zero-fills them once never pays the two
@@ -258,6 +258,18 @@ int gdn_mlp_train_bwd(const float* d_out, const float* act, const float* const* 
                       const float* out_w, int rows, int d_in, int hidden, int layers,
                       const void* saved, void* workspace, float* const* grads, float* d_out_w,
                       float* d_out_b, float* d_act, void* stream);
+
+/* One launch less at the end of a training step: gdn_head_train_bwd_rng with (buffers_zeroed | 2) leaves out its
+ * small finishing launch, gdn_project_bwd_partials is gdn_project_bwd without its reduce launch (*rows_out =
+ * partial rows written to `workspace`), and gdn_train_finish runs both reductions as ONE launch (independent
+ * workgroups, disjoint outputs).  Same results as the separate forms.                                       */
+int gdn_project_bwd_partials(const float* x, const float* d_xlin, const float* d_si, const float* d_sj,
+                             int batch, int n, int w, int d, float* workspace, int* rows_out,
+                             void* stream);
+int gdn_train_finish(double* head_workspace, double* stats, int head_zeroed, int batch, int n, int d,
+                     float* d_emb, float* d_bn1_w, float* d_bn1_b, float* d_bn2_w, float* d_bn2_b,
+                     float* d_lin_w, float* d_lin_b, const float* proj_workspace, int proj_rows, int w,
+                     float* d_proj_w, float* d_a, float* d_c, void* stream);
 
 /* gdn_adam_step: torch.optim.Adam(lr, betas, eps, weight_decay) of train.py:31,73 over ONE flat fp32
  * buffer holding every parameter back to back (params / grads / exp_avg / exp_avg_sq: [count]); step[0] =
