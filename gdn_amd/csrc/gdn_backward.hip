@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void gdn_project_reduce_kernel(const float* __
 // Chain rule through the folded constants a = lin^T att (node_terms) and c = emb . att_em:
 // d_lin_w += att_i (x) d_a[0] + att_j (x) d_a[1];  d_att = lin_w d_a;  d_att_em = emb^T d_c;
 // d_emb = d_c[0] (x) att_em_i + d_c[1] (x) att_em_j.  Tiny ([d,w], [n,d]); one launch instead of a dozen.
-__global__ __launch_bounds__(256) void gdn_terms_bwd_kernel(
+__global__ __launch_bounds__(1024) void gdn_terms_bwd_kernel(
     const float* __restrict__ lin_w, const float* __restrict__ att_i, const float* __restrict__ att_j,
     const float* __restrict__ att_em_i, const float* __restrict__ att_em_j, const float* __restrict__ emb,
     const float* __restrict__ d_a, const float* __restrict__ d_c, int n, int d, int w,
@@ -457,19 +457,20 @@ __global__ __launch_bounds__(256) void gdn_terms_bwd_kernel(
     float* __restrict__ d_att_em_i, float* __restrict__ d_att_em_j, float* __restrict__ d_emb,
     int accumulate_emb) {
   const int tid = threadIdx.x;
-  for (int t = blockIdx.x * 256 + tid; t < n * d; t += gridDim.x * 256) {
+  constexpr int NT = 1024;   // block 0's column sums are chains of dependent-latency loads: 16 row groups, not 4
+  for (int t = blockIdx.x * NT + tid; t < n * d; t += gridDim.x * NT) {
     const int s = t / d, c = t - s * d;
     const float v = fmaf(d_c[s], att_em_i[c], d_c[n + s] * att_em_j[c]);
     d_emb[t] = accumulate_emb ? d_emb[t] + v : v;   // (+ the head's share, written there by gdn_head_train_bwd)
   }
   if (blockIdx.x != 0) return;
-  __shared__ float part[4][256];
-  for (int t = tid; t < d * w; t += 256) {
+  __shared__ float part[4][NT];
+  for (int t = tid; t < d * w; t += NT) {
     const int c = t / w, q = t - c * w;
     d_lin_w[t] += fmaf(att_i[c], d_a[q], att_j[c] * d_a[GDN_A_PITCH + q]);
   }
   // column c is handled by the 256/d threads tid = c, c+d, ...: strided partial sums, then an LDS reduce
-  const int c = tid % d, g = tid / d, groups = 256 / d;
+  const int c = tid % d, g = tid / d, groups = NT / d;
   float si = 0.f, sj = 0.f, ei = 0.f, ej = 0.f;
   // (independent loads, eight iterations in flight: left rolled, the two loops were ~35 dependent L2 round
   // trips and the kernel took 15 us of a 218 us training step)
@@ -675,9 +676,9 @@ extern "C" int gdn_terms_bwd_acc(const float* lin_w, const float* att_i, const f
       !d_att_j || !d_att_em_i || !d_att_em_j || !d_emb || n <= 0 || d <= 0 || w <= 0)
     return GDN_ERR_ARG;
   if (w > GDN_MAX_W || d > 256 || (256 % d) != 0) return GDN_ERR_UNSUPPORTED;
-  int grid = (n * d + 256 * 8 - 1) / (256 * 8);
+  int grid = (n * d + 1024 * 2 - 1) / (1024 * 2);
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(gdn_terms_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, lin_w, att_i, att_j,
+  hipLaunchKernelGGL(gdn_terms_bwd_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, lin_w, att_i, att_j,
                      att_em_i, att_em_j, emb, d_a, d_c, n, d, w, d_lin_w, d_att_i, d_att_j, d_att_em_i,
                      d_att_em_j, d_emb, accumulate_emb);
   return gdn_launch_status();

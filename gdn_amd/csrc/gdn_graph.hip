@@ -69,13 +69,33 @@ __device__ __forceinline__ void graph_row(
     if (cos_out) cos_out[(size_t)i * n + j] = c;
   }
   __syncthreads();
-  // rank by counting: deterministic, n^2 compares per row, no sorting network.
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const float cj = cosrow[j];
-    int rank = 0;
-    for (int l = 0; l < n; ++l) rank += ranks_before(cosrow[l], l, cj, j) ? 1 : 0;
-    rank_of[j] = rank;
-    if (rank < k) topk_idx[(size_t)i * k + rank] = j;
+  // rank by counting: deterministic, n^2 compares per row, no sorting network.  With fewer sensors than threads
+  // the count of one candidate is split over P = blockDim / n threads (integer counts: order does not matter).
+  const int P = (int)blockDim.x / n;
+  if (P <= 1) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const float cj = cosrow[j];
+      int rank = 0;
+      for (int l = 0; l < n; ++l) rank += ranks_before(cosrow[l], l, cj, j) ? 1 : 0;
+      rank_of[j] = rank;
+      if (rank < k) topk_idx[(size_t)i * k + rank] = j;
+    }
+  } else {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) rank_of[j] = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < P * n) {
+      const int j = threadIdx.x % n, part = threadIdx.x / n;
+      const int len = (n + P - 1) / P, l0 = part * len, l1 = min(n, l0 + len);
+      const float cj = cosrow[j];
+      int cnt = 0;
+      for (int l = l0; l < l1; ++l) cnt += ranks_before(cosrow[l], l, cj, j) ? 1 : 0;
+      atomicAdd(&rank_of[j], cnt);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const int rank = rank_of[j];
+      if (rank < k) topk_idx[(size_t)i * k + rank] = j;
+    }
   }
   __syncthreads();
   emit_list(rank_of, i, n, k, pitch, nbr + (size_t)i * pitch, deg + i);
