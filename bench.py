@@ -177,6 +177,25 @@ def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
                     "(profiles/r02_sq_counters*.json)"}
 
 
+def streaming_copy_rate(device, mib=1024, reps=20):
+    """Context for the roofline fractions (quoted against the 8 TB/s spec): what a plain device copy — read N bytes,
+    write N bytes, larger than the 256 MB infinity cache — delivers on THIS GPU, measured the same way (HIP events)."""
+    n = mib * 1024 * 1024 // 4
+    x = torch.rand((n,), device=device)
+    y = torch.empty_like(x)
+    for _ in range(5):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    return {"achieved": round(2 * n * 4 / us / 1e3, 1), "unit": "GB/s", "bytes_each_way": n * 4,
+            "note": "torch tensor copy, read + write; K8's roofline.achieved at the same traffic volume is the comparable figure"}
+
+
 def train_step_line(device, n, w, batch, steps=50):
     """Extra (not the headline): one optimisation step of the reference's train() (train.py:52-66) at the
     same shape — harness.NativeTrainStep: HIP forward/backward, in-kernel dropout draw, gdn_adam_step over flat
@@ -423,6 +442,7 @@ def run():
         preroll(ev2.step)
         result["value_windows_from_raw_series"] = round(t * args.steps / timed(ev2.step, args.steps), 1)
         result["train_step"] = train_step_line(device, n=x.shape[1], w=x.shape[2], batch=args.batch)
+        result["streaming_copy"] = streaming_copy_rate(device)
         if not args.skip_cpu:
             result["cpu_baseline"] = cpu_baseline(params)
     if dist is not None:
