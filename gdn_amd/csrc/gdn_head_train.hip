@@ -88,23 +88,6 @@ __device__ __forceinline__ double repl_sum(const double* p, int stride) {
   return s;
 }
 
-__device__ __forceinline__ BnCols bn_cols(const double* sum, const double* sq, double rows, float eps,
-                                          const float* gamma, const float* beta, int c0) {
-  BnCols r;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const double m = sum[c0 + v] / rows;
-    double var = sq[c0 + v] / rows - m * m;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    r.mu[v] = (float)m;
-    r.is[v] = is;
-    r.sc[v] = gamma[c0 + v] * is;
-    r.be[v] = beta[c0 + v];
-  }
-  return r;
-}
-
 __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
   const float4 t = *reinterpret_cast<const float4*>(p);
   v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -215,25 +198,48 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
     }
   }
 
+  // Per-column constants ONCE per workgroup (one thread per column and BatchNorm: the fp64 divisions and the
+  // square root), handed to the SLOTS lane groups through LDS — computed per thread they were the same ~20 fp64
+  // transcendental sequences 16 times over, a couple of microseconds of every latency-bound pass.
+  __shared__ float colc[12 * D];      // [mu1 | is1 | sc1 | be1 | mu2 | is2 | sc2 | be2 | m2a | m2b | m1a | m1b]
+  if constexpr (MODE >= H_STAT2) {
+    constexpr int NBN = MODE >= H_OUT ? 2 : 1;
+    for (int t = tid; t < NBN * D; t += 256) {
+      const int which = t / D, c = t - which * D;
+      const double* sum = tot + which * 2 * D;
+      const double m = sum[c] / rows;
+      double var = sum[D + c] / rows - m * m;
+      if (var < 0.0) var = 0.0;
+      const float is = (float)(1.0 / sqrt(var + (double)(which ? a.eps2 : a.eps1)));
+      float* dst = colc + which * 4 * D;
+      dst[c] = (float)m;
+      dst[D + c] = is;
+      dst[2 * D + c] = (which ? a.g2 : a.g1)[c] * is;
+      dst[3 * D + c] = (which ? a.b2 : a.b1)[c];
+    }
+    if constexpr (MODE >= H_BWD1) {
+      constexpr int NM = MODE == H_DZ ? 4 : 2;
+      for (int t = tid; t < NM * D; t += 256) colc[8 * D + t] = (float)(tot[4 * D + t] / rows);   // means of d_y2, d_y2 xhat2, d_y1, d_y1 xhat1
+    }
+    __syncthreads();
+  }
   BnCols bn1 = {}, bn2 = {};
-  if constexpr (MODE >= H_STAT2) bn1 = bn_cols(tot, tot + D, rows, a.eps1, a.g1, a.b1, c0);
-  if constexpr (MODE >= H_OUT) bn2 = bn_cols(tot + 2 * D, tot + 3 * D, rows, a.eps2, a.g2, a.b2, c0);
+  if constexpr (MODE >= H_STAT2) {
+    ld4(colc + c0, bn1.mu); ld4(colc + D + c0, bn1.is); ld4(colc + 2 * D + c0, bn1.sc); ld4(colc + 3 * D + c0, bn1.be);
+  }
+  if constexpr (MODE >= H_OUT) {
+    ld4(colc + 4 * D + c0, bn2.mu); ld4(colc + 5 * D + c0, bn2.is); ld4(colc + 6 * D + c0, bn2.sc); ld4(colc + 7 * D + c0, bn2.be);
+  }
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
   if (MODE >= H_OUT && a.w) ld4(a.w + c0, w4);
   float m2a[4] = {}, m2b[4] = {}, m1a[4] = {}, m1b[4] = {};
   if constexpr (MODE >= H_BWD1) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      m2a[v] = (float)(tot[4 * D + c0 + v] / rows);     // mean of d_y2
-      m2b[v] = (float)(tot[5 * D + c0 + v] / rows);     // mean of d_y2 * xhat2
-    }
+    ld4(colc + 8 * D + c0, m2a);      // mean of d_y2
+    ld4(colc + 9 * D + c0, m2b);      // mean of d_y2 * xhat2
   }
   if constexpr (MODE == H_DZ) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      m1a[v] = (float)(tot[6 * D + c0 + v] / rows);
-      m1b[v] = (float)(tot[7 * D + c0 + v] / rows);
-    }
+    ld4(colc + 10 * D + c0, m1a);
+    ld4(colc + 11 * D + c0, m1b);
   }
   double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0}, acc2[4] = {0.0, 0.0, 0.0, 0.0};
   double acc_s = 0.0;
