@@ -637,39 +637,85 @@ __global__ __launch_bounds__(256) void score_smooth_max_kernel(
       const int ca = la ? sa_ : n - 1, cb = lb ? sb_ : n - 1;
       const double meda = med_iqr[2 * ca], dena = fabs(med_iqr[2 * ca + 1]) + 1e-2;
       const double medb = med_iqr[2 * cb], denb = fabs(med_iqr[2 * cb + 1]) + 1e-2;
-      auto norm = [&](int tt, int sc, double med, double den) -> double {   // tt < 0: halo row
-        const float* pp = tt >= 0 ? pred + (size_t)tt * n : halo_pred + (size_t)(3 + tt) * n;
-        const float* gg = tt >= 0 ? gt + (size_t)tt * n : halo_gt + (size_t)(3 + tt) * n;
-        return (fabs((double)pp[sc] - (double)gg[sc]) - med) / den;
+      // ALL 4 x (3 + RUN) values of the run are fetched before the first is used (clamped row indices: the loads are
+      // unconditional, rows that do not exist are masked afterwards) — fetched inside the tick loop they were a
+      // chain of dependent round trips and the kernel ran at 2.2 TB/s
+      const int g0 = first_tick + t0;
+      float pa[RUN + 3], ga[RUN + 3], pb[RUN + 3], gb[RUN + 3];
+#pragma unroll
+      for (int u = 0; u < RUN + 3; ++u) {
+        const int tt = t0 - 3 + u;                 // < 0: halo row 3 + tt (rows before this shard's first tick)
+        const bool halo = tt < 0;
+        const int row = halo ? (first_tick > 0 ? 3 + tt : 0) : min(tt, t - 1);
+        const float* pp = (halo && first_tick > 0 ? halo_pred : pred) + (size_t)row * n;
+        const float* gg = (halo && first_tick > 0 ? halo_gt : gt) + (size_t)row * n;
+        pa[u] = pp[ca]; ga[u] = gg[ca]; pb[u] = pp[cb]; gb[u] = gg[cb];
+      }
+      auto norm = [&](float pv, float gv, double med, double den) -> double {
+        return (fabs((double)pv - (double)gv) - med) / den;
       };
       // the 3 predecessors of t0 that exist in the series (a missing one only feeds ticks whose
       // series index is < 3, which are forced to 0)
-      const int g0 = first_tick + t0;
-      double a3 = g0 >= 3 ? norm(t0 - 3, ca, meda, dena) : 0.0;
-      double a2 = g0 >= 2 ? norm(t0 - 2, ca, meda, dena) : 0.0;
-      double a1 = g0 >= 1 ? norm(t0 - 1, ca, meda, dena) : 0.0;
-      double b3 = g0 >= 3 ? norm(t0 - 3, cb, medb, denb) : 0.0;
-      double b2 = g0 >= 2 ? norm(t0 - 2, cb, medb, denb) : 0.0;
-      double b1 = g0 >= 1 ? norm(t0 - 1, cb, medb, denb) : 0.0;
-#pragma unroll 8
-      for (int tick = t0; tick < t1; ++tick) {
-        const double a0 = norm(tick, ca, meda, dena);
-        const double b0 = norm(tick, cb, medb, denb);
-        double sma = 0.0, smb = 0.0;
-        if (first_tick + tick >= 3) {               // numpy sums the 4 values left to right
-          sma = (((a3 + a2) + a1) + a0) / 4.0;
-          smb = (((b3 + b2) + b1) + b0) / 4.0;
-        }
-        if (scores) {
-          if (la) scores[(size_t)sa_ * t + tick] = sma;
-          if (lb) scores[(size_t)sb_ * t + tick] = smb;
-        }
-        double m = fmax(la ? sma : -INFINITY, lb ? smb : -INFINITY);
+      double a3 = g0 >= 3 ? norm(pa[0], ga[0], meda, dena) : 0.0;
+      double a2 = g0 >= 2 ? norm(pa[1], ga[1], meda, dena) : 0.0;
+      double a1 = g0 >= 1 ? norm(pa[2], ga[2], meda, dena) : 0.0;
+      double b3 = g0 >= 3 ? norm(pb[0], gb[0], medb, denb) : 0.0;
+      double b2 = g0 >= 2 ? norm(pb[1], gb[1], medb, denb) : 0.0;
+      double b1 = g0 >= 1 ? norm(pb[2], gb[2], medb, denb) : 0.0;
+      double mt[RUN];                             // this lane's max over its sensors, per tick of the run
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d));
-        if (lane == 0) best[wv][tick - t0] = s0 == 0 ? m : fmax(best[wv][tick - t0], m);
-        a3 = a2; a2 = a1; a1 = a0;
-        b3 = b2; b2 = b1; b1 = b0;
+      for (int u = 0; u < RUN; ++u) {
+        const int tick = t0 + u;
+        mt[u] = -INFINITY;
+        if (tick < t1) {                           // (wave uniform)
+          const double a0 = norm(pa[3 + u], ga[3 + u], meda, dena);
+          const double b0 = norm(pb[3 + u], gb[3 + u], medb, denb);
+          double sma = 0.0, smb = 0.0;
+          if (first_tick + tick >= 3) {               // numpy sums the 4 values left to right
+            sma = (((a3 + a2) + a1) + a0) / 4.0;
+            smb = (((b3 + b2) + b1) + b0) / 4.0;
+          }
+          if (scores) {
+            if (la) scores[(size_t)sa_ * t + tick] = sma;
+            if (lb) scores[(size_t)sb_ * t + tick] = smb;
+          }
+          mt[u] = fmax(la ? sma : -INFINITY, lb ? smb : -INFINITY);
+          a3 = a2; a2 = a1; a1 = a0;
+          b3 = b2; b2 = b1; b1 = b0;
+        }
+      }
+      // max over the 64 lanes for all 8 ticks together: a butterfly that also transposes — each step a lane keeps
+      // half of its ticks and hands the other half to its partner (8 + 4 + 2 exchanges), then three plain steps on
+      // the one tick left: 20 64-bit exchanges instead of 8 x 6 = 48 (max is exact in any order)
+      static_assert(RUN == 8, "the transposing reduction is written for 8 ticks");
+      double k4[4], k2[2], k1;
+      {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const double mine = up ? mt[4 + i2] : mt[i2], send = up ? mt[i2] : mt[4 + i2];
+          k4[i2] = fmax(mine, __shfl_xor(send, 32));
+        }
+      }
+      {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const double mine = up ? k4[2 + i2] : k4[i2], send = up ? k4[i2] : k4[2 + i2];
+          k2[i2] = fmax(mine, __shfl_xor(send, 16));
+        }
+      }
+      {
+        const bool up = (lane & 8) != 0;
+        const double mine = up ? k2[1] : k2[0], send = up ? k2[0] : k2[1];
+        k1 = fmax(mine, __shfl_xor(send, 8));
+      }
+      k1 = fmax(k1, __shfl_xor(k1, 4));
+      k1 = fmax(k1, __shfl_xor(k1, 2));
+      k1 = fmax(k1, __shfl_xor(k1, 1));
+      if ((lane & 7) == 0) {                       // lanes 0, 8, .., 56 hold ticks 0, 1, .., 7 of the run
+        const int u = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+        best[wv][u] = s0 == 0 ? k1 : fmax(best[wv][u], k1);
       }
     }
     // (LDS writes above and reads below are by the same wave, in program order)
