@@ -635,8 +635,12 @@ __global__ __launch_bounds__(256) void score_smooth_max_kernel(
       const int sa_ = s0 + lane, sb_ = s0 + 64 + lane;
       const bool la = sa_ < n, lb = sb_ < n;
       const int ca = la ? sa_ : n - 1, cb = lb ? sb_ : n - 1;
-      const double meda = med_iqr[2 * ca], dena = fabs(med_iqr[2 * ca + 1]) + 1e-2;
-      const double medb = med_iqr[2 * cb], denb = fabs(med_iqr[2 * cb + 1]) + 1e-2;
+      // (x - median) / (|iqr| + eps), evaluate.py:60-62: the divisor is one number per sensor, so the wave divides
+      // ONCE per sensor and run and multiplies per tick (a float64 division is ~35 instructions; eleven per sensor
+      // and run were a third of this kernel).  x * (1/d) is within one ulp of x / d: 2e-16 relative, four orders
+      // below the 1e-12 bar of the scoring parity tests.
+      const double meda = med_iqr[2 * ca], dena = 1.0 / (fabs(med_iqr[2 * ca + 1]) + 1e-2);
+      const double medb = med_iqr[2 * cb], denb = 1.0 / (fabs(med_iqr[2 * cb + 1]) + 1e-2);
       // ALL 4 x (3 + RUN) values of the run are fetched before the first is used (clamped row indices: the loads are
       // unconditional, rows that do not exist are masked afterwards) — fetched inside the tick loop they were a
       // chain of dependent round trips and the kernel ran at 2.2 TB/s
@@ -651,8 +655,8 @@ __global__ __launch_bounds__(256) void score_smooth_max_kernel(
         const float* gg = (halo && first_tick > 0 ? halo_gt : gt) + (size_t)row * n;
         pa[u] = pp[ca]; ga[u] = gg[ca]; pb[u] = pp[cb]; gb[u] = gg[cb];
       }
-      auto norm = [&](float pv, float gv, double med, double den) -> double {
-        return (fabs((double)pv - (double)gv) - med) / den;
+      auto norm = [&](float pv, float gv, double med, double inv_den) -> double {
+        return (fabs((double)pv - (double)gv) - med) * inv_den;
       };
       // the 3 predecessors of t0 that exist in the series (a missing one only feeds ticks whose
       // series index is < 3, which are forced to 0)
