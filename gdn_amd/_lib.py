@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -63,9 +63,9 @@ SIGNATURES = {
     "gdn_attn_aggregate_fwd_bf16": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_head_fwd_bf16": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_forward_fused_bf16": [_p] * 11 + [_c_int] * 5 + [_p, _p],
-    "gdn_attn_aggregate_bwd": [_p] * 8 + [_c_int] * 4 + [_p] * 5,
+    "gdn_attn_aggregate_bwd": [_p] * 8 + [_c_int] * 4 + [_p] * 6,
     "gdn_attn_aggregate_bwd_workspace_bytes": [_c_int] * 4,
-    "gdn_attn_aggregate_bwd_ws": [_p] * 8 + [_c_int] * 4 + [_p] * 6,
+    "gdn_train_supported": [_c_int] * 4,
     "gdn_rev_pitch": [_c_int],
     "gdn_graph_reverse": [_p, _p, _c_int, _c_int, _p, _p, _p],
     "gdn_project_bwd_workspace_bytes": [_c_int, _c_int, _c_int],

@@ -97,7 +97,7 @@ __device__ __forceinline__ void axpy_steps(const char* tile_lane, float a, int r
 
 struct BwdPlan {
   int n, d, k, pitch, rpitch, batch;
-  int off_tile, off_sj, off_si, off_al, off_dpi, off_dbias, off_nbr;  // float offsets
+  int off_tile, off_sj, off_si, off_al, off_dpi, off_dbias, off_nbr, off_red;  // float offsets
   int lds_bytes;
 };
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     const float* __restrict__ alpha, const float* __restrict__ s_i, const float* __restrict__ s_j,
     const uint16_t* __restrict__ nbr, const uint32_t* __restrict__ rent, const int32_t* __restrict__ rlen,
     float* __restrict__ d_xlin, float* __restrict__ d_si, float* __restrict__ d_sj,
-    float* __restrict__ d_bias, float* __restrict__ dpi_ws) {
+    float* __restrict__ d_bias, float* __restrict__ dpi_ws, float* __restrict__ bias_ws) {
   using G = GeoB<D>;
   constexpr int BL = 2048 / NT;
   extern __shared__ float4 smem_b4[];
@@ -214,10 +214,12 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
             const float pi = sti + sj[j];
             const float dpi = de * (pi > 0.f ? 1.f : GDN_NEG_SLOPE);
             dpi_t[p] = dpi;
-            dsi += dpi;
+            dsi += pi > 0.f ? 0.f : de;       // see below: only the negative-logit slots are summed
           }
         }
-        dsi = row16_sum(dsi);
+        // sum_p slope_p de_p = (0.2 - 1) * sum over the slots with a negative logit (the de_p of a target sum to
+        // 0): the cancelling slope-1 terms are never added, a target with positive logits only gets exactly 0
+        dsi = row16_sum(dsi) * (GDN_NEG_SLOPE - 1.f);
         if (l16 == 0 && slice == 0) d_si[row0 + i] = dsi;
       }
     }
@@ -270,10 +272,18 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     }
     __syncthreads();   // tables and tile are rewritten by the next window
   }
-#pragma unroll
-  for (int v = 0; v < G::VEC; ++v) atomicAdd(&dbias[d0 + v], bias_acc.v[v]);
+  // d_bias = column sums of d_z: the lane groups' sums meet in LDS in a fixed order (the tile is free by now),
+  // the workgroups' rows in gdn_colsum_ticket — no floating-point atomics, bitwise reproducible
+  float* gsum = smem + pl.off_red;                      // [tpp][D] then nth floats (the tile itself when it is large enough)
+  stp<G::VEC>(gsum + slot * D + d0, bias_acc);
   __syncthreads();
-  for (int t = tid; t < D; t += nth) atomicAdd(&d_bias[t], dbias[t]);
+  for (int t = tid; t < D; t += nth) {
+    float s = 0.f;
+    for (int q = 0; q < tpp; ++q) s += gsum[q * D + t];
+    dbias[t] = s;
+  }
+  __syncthreads();
+  gdn_colsum_ticket(bias_ws, dbias, D, d_bias, gsum + tpp * D);
 }
 
 // Reverse lists: for source j, the (target i, slot p) pairs with nbr[i][p] == j, in ascending i
@@ -502,15 +512,7 @@ __global__ __launch_bounds__(1024) void gdn_terms_bwd_kernel(
 
 template <typename K>
 int occupancy_grid(K kern, int threads, int lds, int batch) {
-  int nb = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          160 * 1024) != hipSuccess)
-    (void)hipGetLastError();
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb <= 0) {
-    (void)hipGetLastError();
-    nb = 1;
-  }
-  return min(batch, gdn_cu_count() * nb);
+  return min(batch, gdn_cu_count() * gdn_blocks_per_cu(reinterpret_cast<const void*>(kern), threads, lds));
 }
 
 #define GDN_PBWD_MAX_ROWS 1024   // partial rows (= workgroups) of gdn_project_bwd
@@ -540,32 +542,46 @@ static bool bwd_plan(int batch, int n, int d, int k, bool with_tables, BwdPlan* 
   pl->off_dpi = off; off += with_tables ? n * pl->pitch : 0;
   pl->off_dbias = off; off += d;
   pl->off_nbr = off; off += with_tables ? n * pl->pitch / 2 : 0;   // u16 lists
+  // end-of-kernel d_bias reduction: [lane groups <= 32][d] partial rows + one float per thread (<= 512); it
+  // borrows the tile when that is large enough (every window is done by then)
+  const int red = 32 * (d < 64 ? d : 64) + 512;
+  if ((n + 1) * d >= red) pl->off_red = pl->off_tile;
+  else { pl->off_red = off; off += red; }
   pl->lds_bytes = off * 4;
   return pl->lds_bytes <= 160 * 1024;
 }
 
+// workspace = [ticket + GDN_COLSUM_MAX_ROWS partial rows of d_bias][d_pi tables when they do not fit LDS]
+static long long bwd_bias_ws_floats(int d) { return GDN_COLSUM_WS_HEAD + (long long)GDN_COLSUM_MAX_ROWS * d; }
+
 extern "C" long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, int d, int k) {
   if (batch <= 0 || n <= 0 || k <= 0 || k > n || d <= 0) return 0;
   BwdPlan pl;
-  if (bwd_plan(batch, n, d, k, true, &pl)) return 0;                   // everything fits in LDS
-  return (long long)batch * n * gdn_nbr_pitch(k) * (long long)sizeof(float);
+  long long floats = bwd_bias_ws_floats(d);
+  if (!bwd_plan(batch, n, d, k, true, &pl)) floats += (long long)batch * n * gdn_nbr_pitch(k);   // tables beyond LDS
+  return floats * (long long)sizeof(float);
 }
 
-// 1 when gdn_attn_aggregate_bwd[_ws] reads the reverse lists (gdn_graph_reverse) at this shape, 0 when it runs
+// GDN_BWD_PATH=valu (read once per process) keeps the row-gather backward at every shape (A/B runs)
+static bool gdn_bwd_valu_forced() {
+  static const bool valu_bwd = [] { const char* e = getenv("GDN_BWD_PATH"); return e && e[0] == 'v'; }();
+  return valu_bwd;
+}
+
+// 1 when gdn_attn_aggregate_bwd reads the reverse lists (gdn_graph_reverse) at this shape, 0 when it runs
 // the matrix-core backward, which does not (rent / rlen may then be null and the launch can be skipped)
 extern "C" int gdn_attn_aggregate_bwd_uses_reverse(int n, int d, int k) {
-  static const bool valu_bwd = [] { const char* e = getenv("GDN_BWD_PATH"); return e && e[0] == 'v'; }();
   if (n <= 0 || k <= 0 || k > n) return 1;
-  return (d == 64 && !valu_bwd && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k)) ? 0 : 1;
+  return (d == 64 && !gdn_bwd_valu_forced() && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k)) ? 0 : 1;
 }
 
-extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, const float* alpha,
-                                         const float* s_i, const float* s_j, const uint16_t* nbr,
-                                         const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
-                                         int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
-                                         float* workspace, void* stream) {
-  if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !d_xlin || !d_si || !d_sj || !d_bias || batch <= 0 ||
-      n <= 0 || k <= 0)
+extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
+                                      const float* s_i, const float* s_j, const uint16_t* nbr,
+                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                      float* workspace, void* stream) {
+  if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !d_xlin || !d_si || !d_sj || !d_bias || !workspace ||
+      batch <= 0 || n <= 0 || k <= 0)
     return GDN_ERR_ARG;
   if ((!rent || !rlen) && gdn_attn_aggregate_bwd_uses_reverse(n, d, k)) return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
@@ -573,21 +589,22 @@ extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, co
   BwdPlan pl;
   bool glb = false;
   if (!bwd_plan(batch, n, d, k, true, &pl)) {
-    // tables through global memory: needs the workspace, and the tile alone must still fit
-    if (!workspace || !bwd_plan(batch, n, d, k, false, &pl)) return GDN_ERR_UNSUPPORTED;
+    // tables through global memory (the workspace behind the d_bias rows); the tile alone must still fit
+    if (!bwd_plan(batch, n, d, k, false, &pl)) return GDN_ERR_UNSUPPORTED;
     glb = true;
   }
   hipStream_t st = (hipStream_t)stream;
+  float* dpi_ws = workspace + bwd_bias_ws_floats(d);
   const bool wide = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
-  // matrix-core shapes: both halves of the backward as dense products (gdn_forward_dense.hip).
-  // GDN_BWD_PATH=valu keeps the row-gather kernel below (A/B runs)
+  // matrix-core shapes: both halves of the backward as dense products (gdn_forward_dense.hip)
   if (!gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
-    return gdn_dense_attn_bwd(d_z, xlin, alpha, s_i, s_j, nbr, batch, n, k, d_xlin, d_si, d_sj, d_bias, st);
+    return gdn_dense_attn_bwd(d_z, xlin, alpha, s_i, s_j, nbr, batch, n, k, d_xlin, d_si, d_sj, d_bias, workspace, st);
 #define GDN_BWD_NT(DD, NT, GL)                                                                        \
   {                                                                                                   \
-    const int grid = occupancy_grid(gdn_attn_bwd_kernel<DD, NT, GL>, NT, pl.lds_bytes, batch);        \
+    const int grid = min(occupancy_grid(gdn_attn_bwd_kernel<DD, NT, GL>, NT, pl.lds_bytes, batch),    \
+                         GDN_COLSUM_MAX_ROWS);                                                        \
     hipLaunchKernelGGL((gdn_attn_bwd_kernel<DD, NT, GL>), dim3(grid), dim3(NT), pl.lds_bytes, st, pl, d_z, xlin, \
-                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias, workspace);      \
+                       alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias, dpi_ws, workspace); \
   }
 #define GDN_BWD(DD)                                                   \
   case DD:                                                            \
@@ -606,13 +623,17 @@ extern "C" int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, co
   return gdn_launch_status();
 }
 
-extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
-                                      const float* s_i, const float* s_j, const uint16_t* nbr,
-                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
-                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
-                                      void* stream) {
-  return gdn_attn_aggregate_bwd_ws(d_z, xlin, alpha, s_i, s_j, nbr, rent, rlen, batch, n, d, k, d_xlin, d_si,
-                                   d_sj, d_bias, nullptr, stream);
+// 1 when every kernel of a training step (staged forward, this file's backward) takes the shape: what
+// harness.NativeTrainStep.applicable() asks before it commits to the captured step
+extern "C" int gdn_train_supported(int n, int w, int d, int k) {
+  if (n <= 0 || w <= 0 || k <= 0 || k > n || n > 4096 || k + 1 > 1024 || w > GDN_MAX_W) return 0;
+  if (d != 16 && d != 32 && d != 64 && d != 128) return 0;
+  BwdPlan pl;
+  if (!bwd_plan(1, n, d, k, true, &pl) && !bwd_plan(1, n, d, k, false, &pl)) return 0;
+  const int wp = w <= 8 ? 8 : ((w + 15) & ~15);
+  int rc = (24576 - 2 * n) / (wp + d + 2);                  // gdn_project_bwd's staging chunk
+  if (rc < 1) return 0;
+  return gdn_forward_staged_ok(n, w, d, k);
 }
 
 extern "C" long long gdn_project_bwd_workspace_bytes(int n, int w, int d) {

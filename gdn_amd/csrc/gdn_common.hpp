@@ -15,18 +15,17 @@ static inline int gdn_launch_status() {
   return hipGetLastError() == hipSuccess ? GDN_OK : GDN_ERR_LAUNCH;
 }
 
-static inline int gdn_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+// Immutable device properties, cached per device behind a mutex (gdn_graph.hip): the library is re-entrant
+// across threads, streams and devices.  gdn_blocks_per_cu = resident workgroups per CU of kernel `fn` at
+// (threads, dynamic LDS bytes); it also raises the kernel's dynamic-LDS limit to the 160 KB of a gfx950 CU.
+int gdn_cu_count();
+int gdn_blocks_per_cu(const void* fn, int threads, int lds);
+// environment knob of a diagnostic A/B run, read ONCE per process at its first use (a function-local static:
+// thread-safe initialisation, nothing on the launch path afterwards)
+#define GDN_ENV_INT_ONCE(NAME, FALLBACK) \
+  ([]() -> int { static const int v = [] { const char* e = getenv(NAME); return e ? atoi(e) : (FALLBACK); }(); return v; }())
 
+int gdn_forward_staged_ok(int n, int w, int d, int k);        // gdn_forward.hip: the staged forward takes the shape
 // gdn_forward_dense.hip: the matrix-core aggregation path (n <= 127, d = 64); x is fp32 or bf16 bits
 bool gdn_dense_supported(int n, int w, int d, int k);         // staged kernels: d = 64
 bool gdn_dense_fused_supported(int n, int w, int d, int k);   // fused kernel: d = 64 or 128
@@ -40,7 +39,7 @@ int gdn_dense_attn_aggregate(const void* xlin, int is_bf16, const float* s_i, co
                              hipStream_t stream);
 int gdn_dense_attn_bwd(const float* d_z, const float* xlin, const float* alpha, const float* s_i, const float* s_j,
                        const uint16_t* nbr, int batch, int n, int k, float* d_xlin, float* d_si, float* d_sj,
-                       float* d_bias, hipStream_t stream);        // matrix-core backward of the gather-aggregate
+                       float* d_bias, float* bias_ws, hipStream_t stream);   // matrix-core backward of the gather-aggregate
 int gdn_dense_project(const void* x, int is_bf16, const float* lin_w, const float* node_terms, int batch, int n,
                       int w, int d, void* xlin, float* s_i, float* s_j, hipStream_t stream);
 // run-time choice between the two fused forward implementations: GDN_FUSED_PATH=valu keeps the fp32 VALU
@@ -100,6 +99,58 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
+}
+
+// Fixed-order column sum across the workgroups of a launch, no floating-point atomics: every workgroup stores its
+// row of `cols` partial sums (`lds_row`, complete and visible to the workgroup: call after a barrier), takes a
+// ticket, and the workgroup that draws the last one adds the rows IN ROW ORDER and writes out[cols].  The result
+// depends on the grid size only, never on the order the workgroups finish in: bitwise reproducible.
+//   ws: [0..3] = the ticket (u64 + padding; zero on entry, left zero), rows at ws + 4 + row * cols.
+// Same memory protocol as gdn_mse_kernel: agent-scope stores acknowledged (vmcnt) before the ticket is drawn, the
+// last workgroup reads the rows back with agent-scope loads (no release/acquire fence: each would write back an
+// XCD's whole L2).  Must be reached by every thread of every workgroup; `scratch` = blockDim.x floats of LDS.
+#define GDN_COLSUM_WS_HEAD 4
+#define GDN_COLSUM_MAX_ROWS 1024   // launches that use it keep their grid at or below this
+__device__ __forceinline__ void gdn_colsum_ticket(float* __restrict__ ws, const float* lds_row, int cols,
+                                                  float* __restrict__ out, float* scratch) {
+  __shared__ bool last_wg;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  float* rows = ws + GDN_COLSUM_WS_HEAD;
+  for (int c = tid; c < cols; c += nth)
+    __hip_atomic_store(rows + (size_t)blockIdx.x * cols + c, lds_row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws);
+    const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_wg = t == (unsigned long long)gridDim.x - 1ull;
+    if (last_wg) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last_wg) return;
+  // lane groups take rows g, g + groups, ...; four independent chains each so the loads overlap
+  const int groups = nth / cols > 0 ? nth / cols : 1;
+  const int c = tid % cols, g = tid / cols;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (g < groups) {
+    const int nrow = (int)gridDim.x;
+    int r = g;
+    for (; r + 3 * groups < nrow; r += 4 * groups) {
+      s0 += __hip_atomic_load(rows + (size_t)r * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s1 += __hip_atomic_load(rows + (size_t)(r + groups) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s2 += __hip_atomic_load(rows + (size_t)(r + 2 * groups) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s3 += __hip_atomic_load(rows + (size_t)(r + 3 * groups) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (; r < nrow; r += groups)
+      s0 += __hip_atomic_load(rows + (size_t)r * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  scratch[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (tid < cols) {
+    float s = 0.f;
+    for (int q = 0; q < groups; ++q) s += scratch[q * cols + tid];
+    out[tid] = s;
+  }
 }
 
 // Sum of the per-workgroup partial rows of gdn_project_bwd ([rows][D*wp + 128 + 2n] -> d_lin_w[D,w], d_a[2,64],

@@ -1014,12 +1014,12 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   // threads: small tiles run 256-thread workgroups (several per CU), big tiles own the CU
   const int est = base_bytes + (mode != MODE_PROJECT ? nbr_bytes : 0) + n * (pl->wp + 1) * 4;
   *threads = est > 80 * 1024 ? 512 : 256;
-  if (const char* e = getenv("GDN_THREADS")) {   // tuning knob: 256 or 512
-    const int v = atoi(e);
+  {   // tuning knob GDN_THREADS = 256 or 512 (read once per process)
+    const int v = GDN_ENV_INT_ONCE("GDN_THREADS", 0);
     if (v == 256 || v == 512) *threads = v;
   }
   // projection on the matrix cores: d >= 32, w <= 32, whole window staged at once
-  if (mode != MODE_ATTN && d >= 32 && w <= 32 && !getenv("GDN_NO_MFMA")) {
+  if (mode != MODE_ATTN && d >= 32 && w <= 32 && !GDN_ENV_INT_ONCE("GDN_NO_MFMA", 0)) {
     const int wpm = w <= 16 ? 16 : 32;
     const int xs_bytes = n * (wpm + 1) * 4;
     const int need = base_bytes + xs_bytes;
@@ -1063,27 +1063,11 @@ template <int D, int MODE, int NT, int PROJ, int LST>
 int launch_window(const Plan& pl, const Args& a, hipStream_t stream) {
   constexpr int threads = NT;
   auto kern = gdn_window_kernel<D, MODE, NT, PROJ, LST>;
-  static bool attr_set = false;
-  static int occ_cache_lds = -1, occ = 0;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      (void)hipGetLastError();
-    attr_set = true;
-  }
-  if (occ_cache_lds != pl.lds_bytes) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, pl.lds_bytes) != hipSuccess ||
-        nb <= 0) {
-      (void)hipGetLastError();
-      nb = 1;
-    }
-    occ = nb; occ_cache_lds = pl.lds_bytes;
-  }
+  const int occ = gdn_blocks_per_cu(reinterpret_cast<const void*>(kern), threads, pl.lds_bytes);
   // every workgroup pays a prologue (neighbour lists, weights, constants): give each at least
   // GDN_MIN_WINDOWS_PER_WG windows when the launch is small (concurrent launches on other streams
   // fill the remaining slots)
-  static const int min_wpw = getenv("GDN_MIN_WINDOWS_PER_WG") ? atoi(getenv("GDN_MIN_WINDOWS_PER_WG")) : 1;
+  const int min_wpw = max(1, GDN_ENV_INT_ONCE("GDN_MIN_WINDOWS_PER_WG", 1));
   const int grid = max(1, min((pl.batch + min_wpw - 1) / min_wpw, gdn_cu_count() * occ));
   hipLaunchKernelGGL(kern, dim3(grid, pl.nslices), dim3(threads), pl.lds_bytes, stream, pl, a);
   return gdn_launch_status();
@@ -1140,6 +1124,13 @@ int dispatch_window(const Plan& pl, const Args& a, int threads, hipStream_t stre
 }
 
 }  // namespace
+
+// 1 when the staged forward (gdn_project_fwd + gdn_attn_aggregate_fwd) takes this shape
+int gdn_forward_staged_ok(int n, int w, int d, int k) {
+  Plan pl; int threads;
+  return make_plan(MODE_PROJECT, 1, n, w, d, 0, &pl, &threads) == GDN_OK &&
+         make_plan(MODE_ATTN, 1, n, 0, d, k, &pl, &threads) == GDN_OK;
+}
 
 extern "C" int gdn_project_fwd(const float* x, const float* lin_w, const float* node_terms, int batch,
                                int n, int w, int d, float* xlin, float* s_i, float* s_j, void* stream) {

@@ -32,7 +32,6 @@
 // to LDS after E.
 #include "gdn_common.hpp"
 
-#include <mutex>
 #include <stdlib.h>
 
 int gdn_dense_fused_op_d128(int op, const void* args, int bf16, unsigned* plan_out, long long* bytes,
@@ -950,7 +949,8 @@ struct BwArgs {
   float* d_xlin;           // [BN, 64]
   float* d_si;             // [BN]
   float* d_sj;
-  float* d_bias;           // [64], accumulated with atomics (as gdn_attn_aggregate_bwd)
+  float* d_bias;           // [64], written (fixed-order sum of the workgroups' partial rows: gdn_colsum_ticket)
+  float* bias_ws;          // ticket + [grid][64] partial rows
 };
 
 template <int NT, int SL>
@@ -1189,15 +1189,20 @@ if (b == (int)blockIdx.x) { GDN_STAMP(25) }
 #pragma unroll
       for (int q = 0; q < SL; ++q) dot = fmaf(al[q], g[q], dot);
       dot += dpp_f<GDN_DPP_XOR1>(dot);
+      // d_s_i = sum_q slope_q de_q.  The de_q of a target sum to 0 (softmax), so sum_q slope_q de_q =
+      // (0.2 - 1) * sum over the slots with a NEGATIVE logit: the slope-1 terms, whose sum is pure rounding noise
+      // when they cancel, are never added.  A target whose logits are all positive gets its exact gradient, 0
+      // (near-uniform attention at initialisation: most targets), instead of ~1e-7 of its largest term.
       float dsi = 0.f;
 #pragma unroll
       for (int q = 0; q < SL; ++q) {
         const float de = al[q] * (g[q] - dot);
-        dl[q] = de * ((sti + sjv[q]) > 0.f ? 1.f : GDN_NEG_SLOPE);
-        dsi += dl[q];
+        const bool pos = (sti + sjv[q]) > 0.f;
+        dl[q] = pos ? de : de * GDN_NEG_SLOPE;
+        dsi += pos ? 0.f : de;
       }
       dsi += dpp_f<GDN_DPP_XOR1>(dsi);
-      if (half == 0 && ti < n) a.d_si[(size_t)b * n + ti] = dsi * unscale;
+      if (half == 0 && ti < n) a.d_si[(size_t)b * n + ti] = dsi * ((GDN_NEG_SLOPE - 1.f) * unscale);
     }
 if (b == (int)blockIdx.x) { GDN_STAMP(26) }
     // DL[target][source] takes the place of G: the wave clears its own 32 rows (its gathers are done: LDS is
@@ -1306,11 +1311,14 @@ if (b == (int)blockIdx.x) { GDN_STAMP(31) }
 #pragma unroll
   for (int v = 0; v < 4; ++v) red[(tid / 16) * 64 + ppc * 4 + v] = bsum[v];
   __syncthreads();
+  float* brow = reinterpret_cast<float*>(smem + C::OFF_DZ);
   if (tid < 64) {
     float t = 0.f;
     for (int r = 0; r < C::THREADS / 16; ++r) t += red[r * 64 + tid];
-    atomicAdd(&a.d_bias[tid], t);
+    brow[tid] = t;
   }
+  __syncthreads();
+  gdn_colsum_ticket(a.bias_ws, brow, 64, a.d_bias, reinterpret_cast<float*>(smem + C::OFF_A));
   GDN_STAMP(34)
 }
 
@@ -1461,46 +1469,9 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_project_kernel(const PArgs 
 #endif  // GDN_DENSE_EXTRA_DC
 
 // ------------------------------------------------------------------ host side
-struct OccKey {
-  const void* fn;
-  int dev;
-  int blocks;
-};
-std::mutex g_occ_mutex;
-OccKey g_occ[64];
-int g_occ_count = 0;
-
-// resident workgroups per CU of `fn` at its launch configuration, cached per (kernel, device)
-int blocks_per_cu(const void* fn, int threads, int lds) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  std::lock_guard<std::mutex> lock(g_occ_mutex);
-  for (int i = 0; i < g_occ_count; ++i)
-    if (g_occ[i].fn == fn && g_occ[i].dev == dev) return g_occ[i].blocks;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-    (void)hipGetLastError();
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb <= 0) {
-    (void)hipGetLastError();
-    nb = 1;
-  }
-  if (g_occ_count < 64) g_occ[g_occ_count++] = {fn, dev, nb};
-  return nb;
-}
-
-int cu_count() {
-  int dev = 0;
-  hipDeviceProp_t prop;
-  static std::mutex m;
-  static int cached[16] = {0};
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-  std::lock_guard<std::mutex> lock(m);
-  if (cached[dev] == 0) {
-    cached[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0
-                      ? prop.multiProcessorCount : 256;
-  }
-  return cached[dev];
-}
+// resident workgroups per CU / CU count: the thread-safe per-device caches of gdn_common.hpp
+static inline int blocks_per_cu(const void* fn, int threads, int lds) { return gdn_blocks_per_cu(fn, threads, lds); }
+static inline int cu_count() { return gdn_cu_count(); }
 
 enum { DOP_LAUNCH = 0, DOP_PLAN_BUILD = 1, DOP_PLAN_BYTES = 2 };
 
@@ -1627,7 +1598,7 @@ static int launch_attn_bwd(const BwArgs& a, hipStream_t stream) {
   static_assert(C::LDS <= 160 * 1024, "LDS plan exceeds one CU");
   auto kern = gdn_dense_attn_bwd_kernel<NT, SL>;
   const int occ = blocks_per_cu(reinterpret_cast<const void*>(kern), C::THREADS, C::LDS);
-  const int grid = max(1, min(a.batch, cu_count() * occ));
+  const int grid = max(1, min(min(a.batch, cu_count() * occ), GDN_COLSUM_MAX_ROWS));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
   return gdn_launch_status();
 }
@@ -1645,9 +1616,9 @@ static int attn_bwd_select_sl(const BwArgs& a, hipStream_t st) {
 
 int gdn_dense_attn_bwd(const float* d_z, const float* xlin, const float* alpha, const float* s_i, const float* s_j,
                        const uint16_t* nbr, int batch, int n, int k, float* d_xlin, float* d_si, float* d_sj,
-                       float* d_bias, hipStream_t stream) {
+                       float* d_bias, float* bias_ws, hipStream_t stream) {
   if (!gdn_dense_supported(n, 1, 64, k)) return GDN_ERR_UNSUPPORTED;
-  BwArgs a = {d_z, xlin, alpha, s_i, s_j, nbr, batch, n, gdn_nbr_pitch(k), d_xlin, d_si, d_sj, d_bias};
+  BwArgs a = {d_z, xlin, alpha, s_i, s_j, nbr, batch, n, gdn_nbr_pitch(k), d_xlin, d_si, d_sj, d_bias, bias_ws};
   switch ((n + 1 + 31) / 32) {
     case 1: return attn_bwd_select_sl<1>(a, stream);
     case 2: return attn_bwd_select_sl<2>(a, stream);

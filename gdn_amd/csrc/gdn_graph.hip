@@ -2,6 +2,53 @@
 // microseconds of work, so the kernels favour exactness and determinism over speed).
 #include "gdn_common.hpp"
 
+#include <mutex>
+
+// ------------------------------------------------------------------ cached device properties (thread safe)
+namespace {
+struct OccKey {
+  const void* fn;
+  int dev, threads, lds, blocks;
+};
+std::mutex g_prop_mutex;
+OccKey g_occ[256];
+int g_occ_count = 0;
+int g_cus[32] = {0};
+}  // namespace
+
+int gdn_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+  std::lock_guard<std::mutex> lock(g_prop_mutex);
+  if (g_cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    g_cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0
+                     ? prop.multiProcessorCount : 256;
+  }
+  return g_cus[dev];
+}
+
+int gdn_blocks_per_cu(const void* fn, int threads, int lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(g_prop_mutex);
+  bool seen = false;                      // the dynamic-LDS attribute is per (kernel, device): set it once
+  for (int i = 0; i < g_occ_count; ++i) {
+    if (g_occ[i].fn != fn || g_occ[i].dev != dev) continue;
+    seen = true;
+    if (g_occ[i].threads == threads && g_occ[i].lds == lds) return g_occ[i].blocks;
+  }
+  if (!seen && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    (void)hipGetLastError();
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb <= 0) {
+    (void)hipGetLastError();
+    nb = 1;
+  }
+  if (g_occ_count < 256) g_occ[g_occ_count++] = {fn, dev, threads, lds, nb};
+  return nb;
+}
+
 extern "C" int gdn_abi_version(void) { return GDN_ABI_VERSION; }
 extern "C" int gdn_nbr_pitch(int k) { return ((k + 1) + 15) & ~15; }
 

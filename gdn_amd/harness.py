@@ -675,7 +675,10 @@ class _FlatAdam:
         for p in self.owner.params:
             p.grad = None
 
-    def step(self):
+    def step(self, grad_scale: float = 1.0):
+        """`p.grad` -> the flat gradient buffer -> gdn_adam_step.  The gradients are taken AS THEY ARE: train()
+        has already averaged them over the ranks (sync_gradients), so the 1/ranks the captured step folds into
+        the optimizer kernel must not be applied a second time here."""
         o = self.owner
         with torch.no_grad():
             for p, (off, cnt) in zip(o.params, o.slices):
@@ -683,7 +686,7 @@ class _FlatAdam:
                     o.flat_g[off:off + cnt].copy_(p.grad.reshape(-1))
                 else:
                     o.flat_g[off:off + cnt].zero_()
-        o._adam()
+        o._adam(grad_scale)
         o.model.invalidate_constants()
 
 
@@ -714,6 +717,11 @@ class NativeTrainStep:
         import torch.nn as nn
         if not (type(model.dp) is nn.Dropout and model._hip_train_head_ok() and model.injected_graph is None
                 and next(model.parameters()).is_cuda):
+            return False
+        n, d = model.embedding.weight.shape
+        w = model.gnn_layers[0].gnn.lin.weight.shape[1]
+        from . import _lib
+        if not _lib.load().gdn_train_supported(n, w, d, model.topk):     # shape outside the training kernels
             return False
         # out_layer_num > 1: the OutLayer MLP must be one gdn_mlp_train_fwd takes (any row count > 1)
         return model.out_layer_num == 1 or ops.mlp_train_supported(model.out_layer, model.embedding.weight.shape[1], 2)
@@ -771,6 +779,8 @@ class NativeTrainStep:
             d_z=torch.empty((bn_rows, d), **f32), d_xlin=torch.empty((bn_rows, d), **f32),
             d_si=torch.empty((bn_rows,), **f32), d_sj=torch.empty((bn_rows,), **f32),
             proj_ws=torch.empty((lib.gdn_project_bwd_workspace_bytes(n, w, d) // 4,), **f32),
+            # [ticket (zero, left zero by every call) | d_bias rows | d_pi tables of shapes beyond LDS, e.g. 512 sensors]
+            bwd_ws=torch.zeros((lib.gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, k) // 4,), **f32),
             d_a=torch.empty((128,), **f32), d_c=torch.empty((2 * n,), **f32),
             mse_ws=ops.mse_workspace(dev),
             head_mse_ws=torch.zeros((lib.gdn_head_mse_workspace_bytes() // 8,), dtype=torch.float64, device=dev),
@@ -796,7 +806,6 @@ class NativeTrainStep:
         self._split = world()[1] > 1 if split is None else bool(split)
         name_of = {id(p): name for name, p in model.named_parameters()}
         self._off = {name_of[id(p)]: off for p, (off, _c) in zip(self.params, self.slices)}
-        self._bias_slot = (self._off["gnn_layers.0.gnn.bias"], d)
         self._layer, self._gnn = layer, gnn
 
     # pointers -------------------------------------------------------------------------------------------------
@@ -894,7 +903,7 @@ class NativeTrainStep:
                  p_drop, pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, 1, st)
         main.wait_stream(side2)                      # reverse lists
         call("gdn_attn_aggregate_bwd", pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
-             pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), st)     # slot cleared by Adam
+             pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), pt["bwd_ws"], st)
         if self._mlp is None:
             # partial rows only; their reduction and the head's finishing reduction share ONE launch
             rows = ctypes.c_int(0)
@@ -912,10 +921,13 @@ class NativeTrainStep:
     def _all_reduce(self):
         all_reduce_flat(self.flat_g)
 
-    def _adam(self):
+    def _adam(self, grad_scale: float | None = None):
+        """gdn_adam_step over the flat buffers; `grad_scale` None = 1/ranks (flat_g holds the all-reduced SUM)."""
+        if grad_scale is None:
+            grad_scale = 1.0 / max(1, world()[1])
         self._lib.call("gdn_adam_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                        self.exp_avg_sq.data_ptr(), self.state.data_ptr() + 8, self.count, self.lr, self.BETAS[0],
-                       self.BETAS[1], self.EPS, self.wd, 1.0 / max(1, world()[1]), self._bias_slot[0], self._bias_slot[1],
+                       self.BETAS[1], self.EPS, self.wd, float(grad_scale), 0, 0,
                        torch.cuda.current_stream().cuda_stream)
 
     def _capture(self):

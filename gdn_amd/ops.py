@@ -437,12 +437,15 @@ def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: in
     d_xlin = torch.empty_like(d_z)
     d_si = torch.empty((bn,), dtype=torch.float32, device=d_z.device)
     d_sj = torch.empty_like(d_si)
-    d_bias = torch.zeros((d,), dtype=torch.float32, device=d_z.device)
+    d_bias = torch.empty((d,), dtype=torch.float32, device=d_z.device)
     # the matrix-core backward (n <= 127, d = 64) does not read the reverse lists: they are not even built then
     rent, rlen = graph.reverse() if _lib.load().gdn_attn_aggregate_bwd_uses_reverse(n, d, graph.k) else (None, None)
-    nbytes = _lib.load().gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, graph.k)     # > 0: tables beyond LDS
-    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=d_z.device) if nbytes else None
-    _lib.call("gdn_attn_aggregate_bwd_ws", _ptr(d_z), _ptr(_chk(xlin)), _ptr(_chk(alpha)), _ptr(_chk(s_i)),
+    # [ticket, zero on entry | d_bias partial rows | d_pi tables when they exceed LDS]: a fresh one per call, so
+    # calls on different streams never share a ticket (NativeTrainStep owns one for its stream instead)
+    nbytes = _lib.load().gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, graph.k)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=d_z.device)
+    ws[:4].zero_()
+    _lib.call("gdn_attn_aggregate_bwd", _ptr(d_z), _ptr(_chk(xlin)), _ptr(_chk(alpha)), _ptr(_chk(s_i)),
               _ptr(_chk(s_j)), _ptr(graph.nbr), _ptr(rent), _ptr(rlen), batch, n, d, graph.k,
               _ptr(d_xlin), _ptr(d_si), _ptr(d_sj), _ptr(d_bias), _ptr(ws), _stream())
     return d_xlin, d_si, d_sj, d_bias

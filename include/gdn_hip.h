@@ -25,7 +25,7 @@
  *     column slices) — n up to ~600 at d = 64/128, ~1000 at d = 32, ~2000 at d = 16;
  *   backward (gdn_attn_aggregate_bwd): that tile at full d PLUS two [n, pitch] fp32 tables and the lists
  *     in LDS — n up to ~250 at d = 64 with k = 30 (127-sensor WADI, 51-sensor SWaT, the 25-55-sensor
- *     MSL/SMAP/PSM sets); beyond that gdn_attn_aggregate_bwd_ws keeps the tables in global memory and
+ *     MSL/SMAP/PSM sets); beyond that the tables go through the caller's workspace in global memory and
  *     only the tile must fit (n <= ~600 at d = 64: the 512-sensor / k = 64 stress shape trains);
  *   matrix-core ("dense") kernels — gdn_forward_fused, gdn_project_fwd, gdn_attn_aggregate_fwd pick them
  *     by themselves for n <= 127, d = 64, w <= 32, k <= 63 (gdn_forward_fused also at d = 128); the staged
@@ -46,7 +46,7 @@ extern "C" {
 #define GDN_ERR_LAUNCH (-2)       /* hipGetLastError() != hipSuccess after the launch      */
 #define GDN_ERR_UNSUPPORTED (-3)  /* shape outside the supported set above                 */
 
-#define GDN_ABI_VERSION 19
+#define GDN_ABI_VERSION 20
 int gdn_abi_version(void);
 
 /* Number of u16 slots per neighbour-list row for a given k: (k+1) rounded up to 16. */
@@ -276,7 +276,7 @@ int gdn_train_finish(double* head_workspace, double* stats, int head_zeroed, int
  * steps taken so far (device memory), incremented by the call.  grads are multiplied by grad_scale first
  * (1/ranks after a summing all-reduce).  Same update, in the same operation order, as torch's
  * single-tensor Adam (amsgrad and maximize off).  grads[zero_from, zero_from + zero_count) is cleared
- * after use: the slot of gnn.bias, which gdn_attn_aggregate_bwd accumulates into with atomics.          */
+ * after use (zero_count = 0: nothing is cleared; gdn_attn_aggregate_bwd WRITES its d_bias since ABI 20). */
 int gdn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                   long long* step, int count, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double grad_scale, int zero_from, int zero_count, void* stream);
@@ -396,13 +396,25 @@ int gdn_forward_fused_bf16(const uint16_t* x, const float* lin_w, const float* n
  * the neighbour lists (the graph is built from a detached embedding, models/GDN.py:145).
  *   d_xlin[BN,d]  gradient of the message term (gathered through the reverse lists: no
  *                 scatter atomics, bitwise reproducible);
- *   d_si, d_sj    grads of the per-node scalars; d_bias[d] accumulated with atomics
- *                 (caller zeroes d_bias first).                                         */
+ *   d_si, d_sj    grads of the per-node scalars;
+ *   d_bias[d]     column sums of d_z, WRITTEN (not accumulated): every workgroup leaves one partial row in
+ *                 the workspace and the last one to finish adds the rows in row order — no floating-point
+ *                 atomics anywhere in the backward, so a training step is bitwise reproducible (the true
+ *                 gradient of a bias in front of a train-mode BatchNorm is 0: what arrives here is rounding
+ *                 noise, which Adam turns into +-lr steps — with atomics those steps differed run to run).
+ *   workspace     gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, k) bytes, REQUIRED: [16 bytes: the
+ *                 ticket, ZERO before the first call, left zero by every call][1024 x d floats: the d_bias
+ *                 rows][batch*n*pitch floats of d_pi when the tile plus the two [n, pitch] tables exceed LDS
+ *                 (n ~> 250 at d = 64, k = 30; the 512-sensor / k = 64 stress shape) — the tables then go
+ *                 through global memory and only the tile must fit: (n+1)*d*4 bytes <= ~155 KB].  One
+ *                 workspace per stream: two concurrent calls must not share one.                      */
+long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, int d, int k);
 int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
                            const float* s_i, const float* s_j,
                            const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
                            int batch, int n, int d, int k,
-                           float* d_xlin, float* d_si, float* d_sj, float* d_bias, void* stream);
+                           float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                           float* workspace, void* stream);
 
 /* Shapes on the matrix-core path (n <= 127, d = 64, k <= 63) run the backward as two dense products per
  * window (G = dZ . X^T for d alpha, dX = A^T . dZ for the reverse gather; d_z scaled per window by a power of
@@ -410,18 +422,9 @@ int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alp
  * returns 0 there, rent / rlen may be null and gdn_graph_reverse need not run.                         */
 int gdn_attn_aggregate_bwd_uses_reverse(int n, int d, int k);
 
-/* Large sensor counts: when the tile plus the two [n, pitch] tables exceed LDS (n ~> 250 at d = 64,
- * k = 30; the 512-sensor / k = 64 stress shape), the tables go through global memory and d_pi through a
- * caller workspace of gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, k) bytes (0 = not needed, the
- * plain entry point works).  The tile itself must fit: (n+1) * d * 4 bytes <= ~155 KB (n <= ~600 at
- * d = 64).                                                                                           */
-long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, int d, int k);
-int gdn_attn_aggregate_bwd_ws(const float* d_z, const float* xlin, const float* alpha,
-                              const float* s_i, const float* s_j,
-                              const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
-                              int batch, int n, int d, int k,
-                              float* d_xlin, float* d_si, float* d_sj, float* d_bias,
-                              float* workspace, void* stream);
+/* 1 when every kernel of a training step (gdn_project_fwd, gdn_attn_aggregate_fwd, gdn_attn_aggregate_bwd,
+ * gdn_project_bwd, gdn_terms_bwd) takes the shape, 0 otherwise: ask before capturing a step.           */
+int gdn_train_supported(int n, int w, int d, int k);
 
 /* Reverse neighbour lists for the backward gather: rent[n, gdn_rev_pitch(n)] u32 holds, for
  * source j, (target << 16 | slot) of every list entry that names j, ascending target;

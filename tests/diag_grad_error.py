@@ -33,91 +33,7 @@ from oracle import gdn_oracle  # noqa: E402
 f64 = torch.float64
 
 
-def lists_of(graph):
-    """[n, k+1] source lists in the order of models/graph_layer.py:61-63 (non-self top-k entries, then self),
-    -1 padded, and the validity mask."""
-    n, k = graph.shape
-    out = torch.full((n, k + 1), -1, dtype=torch.long)
-    for i in range(n):
-        src = [int(j) for j in graph[i] if int(j) != i] + [i]
-        out[i, :len(src)] = torch.tensor(src)
-    return out, out >= 0
-
-
-def staged_f64(p, x, y, graph, layers, mask=None):
-    """One training step's forward + backward in float64, stage boundaries kept.  `p`: float64 leaves keyed
-    like state_dict.  Returns (loss, {stage name: tensor}, {stage name: gradient}, {param: gradient})."""
-    b, n, w = x.shape
-    pre = "gnn_layers.0.gnn."
-    lin, emb = p[pre + "lin.weight"], p["embedding.weight"]
-    d = lin.shape[0]
-    a_vec = torch.stack((lin.T @ p[pre + "att_i"].view(d), lin.T @ p[pre + "att_j"].view(d)))        # [2, w]
-    c_vec = torch.stack((emb @ p[pre + "att_em_i"].view(d), emb @ p[pre + "att_em_j"].view(d)))      # [2, n]
-    lin_direct = lin + 0.0                       # the projection's own use of lin (its gradient = "d_lin direct")
-    xlin = x @ lin_direct.T                                                                             # [b, n, d]
-    s_i = x @ a_vec[0] + c_vec[0]
-    s_j = x @ a_vec[1] + c_vec[1]
-    lst, valid = lists_of(graph)
-    safe = lst.clamp(min=0)
-    kinks = {}                                   # smallest |pre-activation| in front of every (Leaky)ReLU
-    pre_logit = s_i.unsqueeze(-1) + s_j[:, safe]
-    kinks["leaky(logit)"] = float(pre_logit.detach()[valid.expand_as(pre_logit)].abs().min())
-    logit = F.leaky_relu(pre_logit, gdn_oracle.NEG_SLOPE)                                                # [b, n, k+1]
-    logit = logit.masked_fill(~valid, float("-inf"))
-    e = (logit - logit.max(dim=-1, keepdim=True).values).exp()
-    alpha = e / (e.sum(dim=-1, keepdim=True) + gdn_oracle.SOFTMAX_EPS)
-    z = (alpha.unsqueeze(-1) * xlin[:, safe]).sum(dim=2) + p[pre + "bias"]                             # [b, n, d]
-    stages = dict(a_vec=a_vec, c_vec=c_vec, lin_direct=lin_direct, xlin=xlin, s_i=s_i, s_j=s_j, z=z)
-    for t in stages.values():
-        t.retain_grad()
-    new_stats = {}
-    h = gdn_oracle.batch_norm(p, "gnn_layers.0.bn.", z.view(b * n, d), True, new_stats)
-    kinks["relu(bn1)"] = float(h.detach().abs().min())
-    h = F.relu(h).view(b, n, d)
-    h = h * emb
-    h = gdn_oracle.batch_norm(p, "bn_outlayer_in.", h.permute(0, 2, 1), True, new_stats)
-    kinks["relu(bn2)"] = float(h.detach().abs().min())
-    h = F.relu(h).permute(0, 2, 1)
-    if mask is not None:
-        h = h * mask
-    act = h + 0.0
-    act.retain_grad()
-    stages["act"] = act
-    hh = act
-    for l in range(layers):                      # gdn_oracle.out_layer, with the pre-activations looked at
-        key = f"out_layer.mlp.{3 * l}."
-        hh = F.linear(hh, p[key + "weight"], p[key + "bias"])
-        if l != layers - 1:
-            hh = gdn_oracle.batch_norm(p, f"out_layer.mlp.{3 * l + 1}.", hh.permute(0, 2, 1), True, new_stats).permute(0, 2, 1)
-            kinks[f"relu(mlp{l})"] = float(hh.detach().abs().min())
-            hh = F.relu(hh)
-    out = hh.view(-1, n)
-    staged_f64.kinks = kinks
-    loss = F.mse_loss(out, y)
-    loss.backward()
-    stage_grads = {k_: v.grad.detach() for k_, v in stages.items()}
-    stages = {k_: v.detach() for k_, v in stages.items()}
-    stages["alpha"] = alpha.detach()
-    stages["out"] = out.detach()
-    grads = {k_: v.grad.detach() for k_, v in p.items() if torch.is_tensor(v) and v.requires_grad}
-    return loss.detach(), stages, stage_grads, grads
-
-
-def rel_err(got, want):
-    """(max |d| / max(|g|, 1e-3 max|g|), max|d| / max|g|, max|g|) of a tensor against its float64 value."""
-    got, want = got.detach().cpu().to(f64).reshape(-1), want.detach().cpu().to(f64).reshape(-1)
-    top = float(want.abs().max())
-    if top == 0.0:
-        return float((got - want).abs().max()), 0.0, 0.0
-    den = torch.clamp(want.abs(), min=1e-3 * top)
-    diff = (got - want).abs()
-    return float((diff / den).max()), float(diff.max()) / top, top
-
-
-def row(name, got, want):
-    e, a, top = rel_err(got, want)
-    print(f"    {name:34s} max|g| {top:9.3e}   rel/element {e:9.2e}   max|d|/max|g| {a:9.2e}")
-    return e
+from _grad_check import lists_of, staged_f64, rel_err, row   # noqa: E402,F401
 
 
 def multi_step(a):
@@ -198,6 +114,8 @@ def main():
     ap.add_argument("--inter", type=int, default=128)
     ap.add_argument("--seed", type=int, default=9)
     ap.add_argument("--cpu-only", action="store_true", help="only check the float64 decomposition against the oracle")
+    ap.add_argument("--init", default="random", help="'default' = the module's own initialisation + att_em ~ U(-0.1, 0.1) "
+                    "(what __graft_entry__.smoke() trains): near-uniform attention, tiny att_i gradients")
     ap.add_argument("--eager", action="store_true", help="multi-step mode: NativeTrainStep without the HIP graph")
     ap.add_argument("--steps", type=int, default=0, help="> 0: the multi-step comparison of the two HIP training paths")
     a = ap.parse_args()
@@ -208,7 +126,16 @@ def main():
     g = torch.Generator().manual_seed(3)
     x = torch.rand((b, n, w), generator=g)
     y = torch.rand((b, n), generator=g)
-    model = random_params(n, w, k, d, seed=a.seed, out_layer_num=a.layers, inter=a.inter)
+    if a.init == "default":
+        from gdn_amd import GDN
+        torch.manual_seed(a.seed)
+        model = GDN([torch.zeros((2, 1), dtype=torch.long)], n, dim=d, input_dim=w, topk=k, out_layer_num=a.layers,
+                    out_layer_inter_dim=a.inter)
+        with torch.no_grad():
+            model.gnn_layers[0].gnn.att_em_i.uniform_(-0.1, 0.1)
+            model.gnn_layers[0].gnn.att_em_j.uniform_(-0.1, 0.1)
+    else:
+        model = random_params(n, w, k, d, seed=a.seed, out_layer_num=a.layers, inter=a.inter)
     params = {key: v.detach().clone() for key, v in model.state_dict().items()}
     graph = gdn_oracle.learned_graph(params["embedding.weight"], k)
 

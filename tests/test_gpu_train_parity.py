@@ -154,42 +154,6 @@ def test_head_train_rejects_single_row(gpu_device):
                            torch.zeros((1, 64), device=gpu_device), torch.zeros((1,), device=gpu_device), None, 1)
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_graphed_train_step_equals_eager_steps(split, gpu_device):
-    """harness.GraphedTrainStep: replaying the captured step trains exactly like launching it eagerly
-    (dropout off so both draw no random numbers), and capturing does not move the parameters.
-    split=True is the multi-rank form (forward+backward graph, eager all-reduce, optimizer graph)."""
-    from gdn_amd.harness import GraphedTrainStep
-    from test_gpu_forward_parity import random_params
-    b = 64
-    g = torch.Generator().manual_seed(5)
-    xs = torch.rand((4, b, 27, 10), generator=g).to(gpu_device)
-    ys = torch.rand((4, b, 27), generator=g).to(gpu_device)
-    finals = []
-    for use_graph in (False, True):
-        model = random_params(27, 10, 8, 64, seed=3).to(gpu_device)
-        model.dp.p = 0.0
-        before = [p.detach().clone() for p in model.parameters()]
-        step = GraphedTrainStep(model, b, use_graph=use_graph, split=split)
-        if use_graph:
-            step._capture()
-            for p, q in zip(model.parameters(), before):
-                assert torch.equal(p, q)
-        losses = []
-        for i in range(4):
-            step.x.copy_(xs[i]); step.y.copy_(ys[i])
-            losses.append(float(step.step()))
-        finals.append((losses, [p.detach().clone() for p in model.parameters()],
-                       [bf.detach().clone() for bf in model.buffers()]))
-    np.testing.assert_allclose(finals[0][0], finals[1][0], atol=1e-6)
-    names = [n for n, _ in model.named_parameters()]
-    for name, pa, pb in zip(names, finals[0][1], finals[1][1]):
-        # gnn.bias has zero true gradient under train-mode BN: Adam turns rounding noise into +-lr steps
-        tol = 4.5e-3 if name.endswith("gnn.bias") else 2e-5
-        np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), atol=tol, err_msg=name)
-    assert min(finals[1][0]) < finals[1][0][0]          # it trains
-
-
 def test_training_forward_follows_unversioned_parameter_writes(gpu_device):
     """Fused optimizers update parameters without bumping `_version`: the train-mode forward must still
     rebuild the sensor graph from the current embedding."""
@@ -224,32 +188,6 @@ def test_harness_train_reproduces_reference_losses(gpu_device):
     loader = [(x[s:s + m["b"]], y[s:s + m["b"]], torch.zeros(m["b"]), None) for s in range(0, x.shape[0], m["b"])]
     losses = harness.train(model, "", {"epoch": 1}, loader, None)
     np.testing.assert_allclose(losses, data["losses"], atol=2e-5, rtol=0)
-
-
-def test_harness_train_graph_mode_matches_eager(gpu_device, tmp_path):
-    """train(use_graph=True): full minibatches replay the captured step, the ragged last batch runs
-    eagerly with the same optimizer; same losses, same checkpoint as the eager loop."""
-    from gdn_amd import harness
-    from test_gpu_forward_parity import random_params
-    g = torch.Generator().manual_seed(11)
-    xs, ys = torch.rand((150, 27, 10), generator=g), torch.rand((150, 27), generator=g)
-    loader = [(xs[s:s + 64], ys[s:s + 64], torch.zeros(len(xs[s:s + 64])), None) for s in range(0, 150, 64)]
-    assert [b[0].shape[0] for b in loader] == [64, 64, 22]
-    val = [(xs[:32], ys[:32], torch.zeros(32), None)]
-    out = {}
-    for mode in (False, True):
-        model = random_params(27, 10, 8, 64, seed=4).to(gpu_device)
-        model.dp.p = 0.0
-        path = str(tmp_path / f"best_{mode}.pt")
-        losses = harness.train(model, path, {"epoch": 2}, loader, val, use_graph=mode)
-        out[mode] = (losses, torch.load(path, weights_only=True))
-    assert len(out[True][0]) == 6
-    np.testing.assert_allclose(out[False][0], out[True][0], atol=2e-5, rtol=0)
-    for key, val_e in out[False][1].items():
-        # zero-gradient bias (see the 2-step test) random-walks by +-lr per step; the BatchNorm behind it
-        # tracks the mean of z, which contains that bias
-        tol = 2e-2 if key.endswith("gnn.bias") or key.endswith("0.bn.running_mean") else 1e-4
-        np.testing.assert_allclose(val_e.cpu().numpy(), out[True][1][key].cpu().numpy(), atol=tol, err_msg=key)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -306,111 +244,30 @@ def test_fused_mse_loss_and_gradient(shape, gpu_device):
     assert float(ws.abs().sum()) >= 0 and int(ws.view(torch.int64)[0]) == 0
 
 
-def test_back_to_back_graph_replays_without_host_sync(gpu_device):
-    """Replays issued back to back (no host synchronisation, as in a real training loop) must train like
-    per-step launches.  Shape = the SWaT one at 4096 windows: torch's multi-block mean reduction (the
-    mse_loss the step used before the fused loss kernel) went wrong exactly here under replay."""
-    from gdn_amd.harness import GraphedTrainStep
-    from test_gpu_forward_parity import random_params
-    b, steps = 4096, 10
-    g = torch.Generator().manual_seed(0)
-    x = torch.rand((b, 127, 15), generator=g).to(gpu_device)
-    y = torch.rand((b, 127), generator=g).to(gpu_device)
-
-    model = random_params(127, 15, 30, 64, seed=0).to(gpu_device).train()
-    model.dp.p = 0.0
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    for _ in range(steps):                                  # plain eager loop, torch loss, synced every step
-        opt.zero_grad()
-        loss = torch.nn.functional.mse_loss(model(x, None), y)
-        loss.backward()
-        opt.step()
-        ref_loss = loss.item()
-    ref_params = [p.detach().clone() for p in model.parameters()]
-
-    model = random_params(127, 15, 30, 64, seed=0).to(gpu_device).train()
-    model.dp.p = 0.0
-    step = GraphedTrainStep(model, b)
-    step.x.copy_(x)
-    step.y.copy_(y)
-    for _ in range(steps):
-        step.step()                                         # no .item(), no synchronize
-    torch.cuda.synchronize()
-    assert abs(float(step.loss) - ref_loss) < 2e-5
-    for (name, p), q in zip(model.named_parameters(), ref_params):
-        tol = 2e-2 if name.endswith("gnn.bias") else 2e-4
-        np.testing.assert_allclose(p.detach().cpu().numpy(), q.cpu().numpy(), atol=tol, err_msg=name)
-
-
 @pytest.mark.parametrize("case", MODEL_CASES)
 def test_train_step_against_float64_oracle(case, gpu_device):
-    """Accuracy rather than parity: the same training step computed by the oracle in float64.  The fp32
-    reference fixture is itself up to 1e-4 away from this on some gradients (train-mode BatchNorm
-    amplifies its rounding); the HIP path must sit within 2e-6 (+1e-5 relative)."""
-    from oracle import gdn_oracle
+    """Accuracy rather than parity: the same training step computed in float64 (tests/_grad_check.py, pinned to
+    the op-faithful oracle by tests/test_oracle_golden.py).  Every gradient is compared RELATIVE to its tensor
+    (max|d| <= 2e-5 max|g|) and to its element (|d| <= 1e-2 max(|g|, 1e-3 max|g|)): the bounds are 6-10x what
+    profiles/r03_grad_error_stages_l3_*.txt measured for the HIP path (3.6e-6 / 7.6e-4) and for the reference's own
+    fp32 arithmetic (2.6e-6 / 4.1e-4).  An absolute 2e-6 — the round-2 bound — is larger than whole attention
+    gradients and saw nothing."""
+    from _grad_check import KINK_BAND, assert_grads_close, oracle_step
     data, p = load_golden(case)
     m = meta(data)
     model = build_model(p, m, gpu_device)
     model.injected_graph = torch.from_numpy(data["learned_graph"]).to(gpu_device)
-    model.dp = FixedMaskDropout([torch.from_numpy(data["dropout_mask"]).to(gpu_device)])
+    mask = torch.from_numpy(data["dropout_mask"])
+    model.dp = FixedMaskDropout([mask.to(gpu_device)])
     model.train()
     model.zero_grad()
     x, y = torch.from_numpy(data["x"]), torch.from_numpy(data["y"])
     loss = torch.nn.functional.mse_loss(model(x.to(gpu_device), None), y.to(gpu_device))
     loss.backward()
-    f64 = torch.float64
-    leaf = {k: (v.to(f64).requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in p.items()}
-    r = gdn_oracle.forward(leaf, x.to(f64), m["k"], m["out_layer_num"], training=True,
-                           dropout_mask=torch.from_numpy(data["dropout_mask"]).to(f64),
-                           graph=torch.from_numpy(data["learned_graph"]))
-    ref_loss = torch.nn.functional.mse_loss(r["out"], y.to(f64))
-    ref_loss.backward()
-    assert abs(loss.item() - ref_loss.item()) < 2e-6
-    for name, prm in model.named_parameters():
-        want = leaf[name].grad.numpy()
-        np.testing.assert_allclose(prm.grad.cpu().numpy().astype(np.float64), want, atol=2e-6, rtol=1e-5,
-                                   err_msg=name)
-
-
-def test_graph_mode_with_even_batches_keeps_validation_fresh(gpu_device, tmp_path):
-    """Every batch is full-size, so a graph-mode epoch runs NO Python forward in train mode: the
-    validation pass after each epoch must still see the parameters the replays wrote (the eval
-    constants cache is keyed on versions a replay never bumps — GraphedTrainStep.step invalidates it).
-    Same per-step losses, validation-selected checkpoint and early-stop bookkeeping as the eager loop."""
-    from gdn_amd import harness
-    from test_gpu_forward_parity import random_params
-    g = torch.Generator().manual_seed(12)
-    xs, ys = torch.rand((128, 27, 10), generator=g), torch.rand((128, 27), generator=g)
-    loader = [(xs[s:s + 64], ys[s:s + 64], torch.zeros(64), None) for s in range(0, 128, 64)]
-    val = [(xs[:32] * 0.5, ys[:32], torch.zeros(32), None)]
-    seen = {}
-    real_test = harness.test
-
-    def spy(model, dataloader, device=None, **kw):
-        loss, res = real_test(model, dataloader, device, **kw)
-        seen.setdefault(spy.mode, []).append(loss)
-        return loss, res
-    harness.test = spy
-    try:
-        out = {}
-        for mode in (False, True):
-            spy.mode = mode
-            model = random_params(27, 10, 8, 64, seed=5).to(gpu_device)
-            model.dp.p = 0.0
-            path = str(tmp_path / f"best_{mode}.pt")
-            losses = harness.train(model, path, {"epoch": 3}, loader, val, use_graph=mode)
-            out[mode] = (losses, torch.load(path, weights_only=True))
-    finally:
-        harness.test = real_test
-    assert len(seen[False]) == len(seen[True]) == 3
-    assert len(set(seen[True])) == 3, "validation loss did not move: stale eval constants"
-    # (two correct runs drift apart by ~1e-5 per epoch: the zero-gradient gnn.bias random-walks by +-lr per Adam
-    # step on rounding noise, see the 2-step test; stale constants would be off by ~1e-2)
-    np.testing.assert_allclose(seen[True], seen[False], atol=1e-4, rtol=0)
-    np.testing.assert_allclose(out[True][0], out[False][0], atol=1e-4, rtol=0)
-    for key, val_e in out[False][1].items():
-        tol = 2e-2 if key.endswith("gnn.bias") or key.endswith("0.bn.running_mean") else 1e-4
-        np.testing.assert_allclose(val_e.cpu().numpy(), out[True][1][key].cpu().numpy(), atol=tol, err_msg=key)
+    ref_loss, want, kink = oracle_step(p, x, y, torch.from_numpy(data["learned_graph"]), m["out_layer_num"], mask)
+    assert kink > KINK_BAND, "fixture has a (Leaky)ReLU input inside the fp32 rounding band: gradients are ambiguous"
+    assert abs(loss.item() - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+    assert_grads_close({name: prm.grad for name, prm in model.named_parameters()}, want, what=case)
 
 
 def test_eval_after_replays_equals_a_fresh_model_with_the_same_state(gpu_device):
@@ -491,66 +348,6 @@ def _mix32_mask(seed, step, count, p_drop, device):
     return x >= int(p_drop * 4294967296.0)
 
 
-@pytest.mark.parametrize("p_drop,layers", [(0.0, 1), (0.2, 1), (0.2, 2), (0.0, 3)])
-def test_native_train_step_equals_the_autograd_step(p_drop, layers, gpu_device):
-    """NativeTrainStep (no autograd, gradients straight into the flat bucket, gdn_adam_step, dropout drawn in the
-    kernels) against the autograd + torch.optim.Adam path fed THE SAME dropout masks (recomputed here from the
-    documented hash): per-step losses, gradients of the first step, parameters after 5 steps."""
-    from gdn_amd import harness
-    from test_gpu_forward_parity import random_params
-    b, n, w, k, d, steps, seed = 48, 27, 10, 8, 64, 5, 1234567890123
-    g = torch.Generator().manual_seed(3)
-    xs = torch.rand((steps, b, n, w), generator=g).to(gpu_device)
-    ys = torch.rand((steps, b, n), generator=g).to(gpu_device)
-
-    model = random_params(n, w, k, d, seed=9, out_layer_num=layers, inter=128).to(gpu_device)
-    model.dp.p = p_drop
-    assert harness.NativeTrainStep.applicable(model)
-    nat = harness.NativeTrainStep(model, b, use_graph=True, seed=seed)
-    assert all(p.data_ptr() >= nat.flat_p.data_ptr() and p.data_ptr() < nat.flat_p.data_ptr() + 4 * nat.count
-               for p in model.parameters())          # the parameters ARE views of the flat buffer
-
-    ref = random_params(n, w, k, d, seed=9, out_layer_num=layers, inter=128).to(gpu_device).train()
-    masks = [(_mix32_mask(seed, t, b * n * d, p_drop, gpu_device).float() / (1.0 - p_drop)).view(b, n, d)
-             for t in range(steps)]
-    ref.dp = FixedMaskDropout(masks)
-    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
-    names = [name for name, _ in ref.named_parameters()]
-    for t in range(steps):
-        nat.x.copy_(xs[t]); nat.y.copy_(ys[t])
-        loss_n = float(nat.step())
-        opt.zero_grad()
-        loss_r = torch.nn.functional.mse_loss(ref(xs[t], None), ys[t])
-        loss_r.backward()
-        if t == 0:
-            for name, prm, (off, cnt) in zip(names, ref.parameters(), nat.slices):
-                if name.endswith("gnn.bias"):
-                    continue        # cleared by the optimizer kernel after use (and its true value is 0)
-                got = nat.flat_g[off:off + cnt].view(prm.shape)
-                np.testing.assert_allclose(got.cpu().numpy(), prm.grad.cpu().numpy(), atol=2e-6, rtol=1e-4, err_msg=name)
-        opt.step()
-        assert abs(loss_n - float(loss_r.detach())) < 2e-6, (t, loss_n, float(loss_r.detach()))
-    assert int(nat.state[1]) == steps
-    for name, pa, pb in zip(names, model.parameters(), ref.parameters()):
-        # parameters whose true gradient is 0 (a bias in front of a train-mode BatchNorm: gnn.bias and the hidden
-        # Linear biases of the MLP) see pure rounding noise, and Adam turns noise of either sign into +-lr steps
-        noise_only = name.endswith("gnn.bias") or (name.startswith("out_layer.mlp.") and name.endswith(".bias")
-                                                   and name != f"out_layer.mlp.{3 * (layers - 1)}.bias")
-        diff = (pa.detach() - pb.detach()).abs()
-        assert float(diff.max()) <= 6e-3, name                          # never more than the 5 steps of size lr
-        if not noise_only:
-            # everything else within 2e-5 — except that single ELEMENTS whose gradient happens to sit at the rounding
-            # level behave like the noise-only parameters: Adam's step is lr * m / sqrt(v) whatever the gradient's size,
-            # so an element with |g| ~ 1e-8 (the run-to-run noise of the fp64 / fp32 atomics in the statistics and
-            # bias reductions) moves by +-lr in a direction that differs between two correct runs.  Seen in ~1 of 3
-            # runs of the 3-layer case, always well under 1 % of a weight matrix: at most 2 % of a tensor may do so.
-            # (The first step's gradients are compared element by element above, at 2e-6.)
-            assert float((diff > 2e-5).float().mean()) <= 2e-2, (name, float(diff.max()))
-    if p_drop > 0:
-        kept = torch.stack(masks).ne(0).float().mean().item()
-        assert abs(kept - (1.0 - p_drop)) < 2e-3         # the draw has the right rate
-
-
 def test_native_step_state_follows_checkpoint_round_trip(gpu_device):
     """Parameters stay ordinary module parameters: state_dict() sees the trained values and a fresh model loaded
     from it predicts what the trained one predicts."""
@@ -574,11 +371,16 @@ def test_native_step_state_follows_checkpoint_round_trip(gpu_device):
         assert torch.equal(model(x, None), fresh(x, None))
 
 
-def test_training_step_at_the_512_sensor_stress_shape(gpu_device):
+@pytest.mark.parametrize("path", ["autograd", "native_graph"])
+def test_training_step_at_the_512_sensor_stress_shape(path, gpu_device):
     """BASELINE configs[4] shape (512 sensors, top-k 64, W=30, d=64): the backward's two [n, pitch] tables
-    (164 KB each) cannot sit in LDS, gdn_attn_aggregate_bwd_ws runs them through global memory.  One training
-    step against the float64 oracle (loss and every gradient); the reference trains at any n."""
-    from oracle import gdn_oracle
+    (164 KB each) cannot sit in LDS, gdn_attn_aggregate_bwd runs them through its workspace in global memory.
+    One training step against float64 (loss and every gradient, relative bounds), through the autograd
+    Functions and through the DEFAULT path of harness.train / python -m gdn_amd.main: the captured
+    NativeTrainStep (round 2 raised GDN_ERR_UNSUPPORTED there).  The reference trains at any n
+    (train.py:58-79)."""
+    from gdn_amd import harness
+    from _grad_check import KINK_BAND, assert_grads_close, oracle_step
     from test_gpu_forward_parity import random_params
     n, w, k, d, b = 512, 30, 64, 64, 2
     model = random_params(n, w, k, d, seed=21)
@@ -586,21 +388,43 @@ def test_training_step_at_the_512_sensor_stress_shape(gpu_device):
     model = model.to(gpu_device).train()
     g = torch.Generator().manual_seed(22)
     x, y = torch.rand((b, n, w), generator=g), torch.rand((b, n), generator=g)
-    mask = (torch.rand((b, n, d), generator=g) >= 0.2).float() / 0.8
-    model.dp = FixedMaskDropout([mask.to(gpu_device)])
-    model.zero_grad()
-    loss = torch.nn.functional.mse_loss(model(x.to(gpu_device), None), y.to(gpu_device))
-    loss.backward()
-    graph = model.learned_graph.cpu()
-    f64 = torch.float64
-    leaf = {key: (v.to(f64).requires_grad_("running" not in key) if v.is_floating_point() else v) for key, v in p.items()}
-    r = gdn_oracle.forward(leaf, x.to(f64), k, training=True, dropout_mask=mask.to(f64), graph=graph)
-    ref_loss = torch.nn.functional.mse_loss(r["out"], y.to(f64))
-    ref_loss.backward()
-    assert abs(loss.item() - ref_loss.item()) < 2e-6
-    for name, prm in model.named_parameters():
-        np.testing.assert_allclose(prm.grad.cpu().numpy().astype(np.float64), leaf[name].grad.numpy(), atol=2e-6,
-                                   rtol=1e-5, err_msg=name)
+    if path == "autograd":
+        mask = (torch.rand((b, n, d), generator=g) >= 0.2).float() / 0.8
+        model.dp = FixedMaskDropout([mask.to(gpu_device)])
+        model.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x.to(gpu_device), None), y.to(gpu_device))
+        loss.backward()
+        got = {name: prm.grad for name, prm in model.named_parameters()}
+        graph = model.learned_graph.cpu()
+    else:
+        seed = 424242
+        assert harness.NativeTrainStep.applicable(model)
+        step = harness.GraphedTrainStep(model, b)
+        assert isinstance(step, harness.NativeTrainStep)
+        step.state[0] = seed
+        mask = (_mix32_mask(seed, 0, b * n * d, 0.2, gpu_device).float() / 0.8).view(b, n, d).cpu()
+        step.x.copy_(x.to(gpu_device)); step.y.copy_(y.to(gpu_device))
+        loss = step.step()
+        got = {name: step.flat_g[off:off + cnt].view(prm.shape)
+               for (name, prm), (off, cnt) in zip(model.named_parameters(), step.slices)}
+        graph = step.ws["topk"].cpu()
+    ref_loss, want, kink = oracle_step(p, x, y, graph, 1, mask)
+    assert kink > KINK_BAND
+    assert abs(float(loss) - ref_loss) < 2e-6
+    assert_grads_close(got, want, what=path)
+
+
+def test_native_step_is_refused_for_shapes_outside_the_training_kernels(gpu_device):
+    """NativeTrainStep.applicable() asks the library (gdn_train_supported) instead of failing at the first batch:
+    a 2000-sensor model at d = 64 (tile beyond LDS) is refused, GraphedTrainStep then builds the autograd step."""
+    from gdn_amd import _lib, harness
+    from test_gpu_forward_parity import random_params
+    assert _lib.load().gdn_train_supported(512, 30, 64, 64) == 1
+    assert _lib.load().gdn_train_supported(127, 15, 64, 30) == 1
+    assert _lib.load().gdn_train_supported(2000, 15, 64, 30) == 0          # (n+1)*d*4 > 160 KB
+    assert _lib.load().gdn_train_supported(127, 15, 48, 30) == 0           # d outside {16, 32, 64, 128}
+    model = random_params(2000, 15, 30, 64, seed=1).to(gpu_device)
+    assert not harness.NativeTrainStep.applicable(model)
 
 
 # ---------------------------------------------------------------- train-mode OutLayer MLP (out_layer_num > 1)
@@ -677,34 +501,6 @@ def test_mlp_head_training_uses_the_hip_mlp(gpu_device, monkeypatch):
         assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
 
 
-def test_native_step_variants_agree(gpu_device, monkeypatch):
-    """The opt-in forms of the native step (loss folded into the head's last forward pass, GDN_FUSE_MSE=1; the
-    row-gather backward, GDN_BWD_PATH is read once per process so only the loss variant is switched here) train
-    exactly like the default: same losses, same parameters after 4 steps (same dropout stream)."""
-    from gdn_amd import harness
-    from test_gpu_forward_parity import random_params
-    b, n, w, k, d = 32, 27, 10, 8, 64
-    g = torch.Generator().manual_seed(5)
-    xs = torch.rand((4, b, n, w), generator=g).to(gpu_device)
-    ys = torch.rand((4, b, n), generator=g).to(gpu_device)
-    results = []
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("GDN_FUSE_MSE", fuse)
-        model = random_params(n, w, k, d, seed=3).to(gpu_device)
-        step = harness.NativeTrainStep(model, b, use_graph=True, seed=99)
-        assert step._fuse_mse == (fuse == "1")
-        losses = []
-        for t in range(4):
-            step.x.copy_(xs[t]); step.y.copy_(ys[t])
-            losses.append(float(step.step()))
-        results.append((losses, step.flat_p.clone()))
-    np.testing.assert_allclose(results[0][0], results[1][0], rtol=0, atol=1e-7)
-    off, cnt = step._bias_slot          # gnn.bias: true gradient 0, summed with float atomics -> +-lr steps of either sign
-    keep = torch.ones_like(results[0][1], dtype=torch.bool)
-    keep[off:off + cnt] = False
-    np.testing.assert_allclose(results[0][1][keep].cpu().numpy(), results[1][1][keep].cpu().numpy(), rtol=0, atol=1e-6)
-
-
 def test_matrix_core_backward_of_the_aggregate_over_random_shapes(gpu_device):
     """gdn_attn_aggregate_bwd on the matrix-core path (n <= 127, d = 64: G = dZ.X^T and dX = A^T.dZ as dense
     products, d_z scaled per window) against float64 autograd of the same layer (graph_layer.py:106-117 in list
@@ -775,24 +571,3 @@ def test_graph_and_terms_single_launch_equals_the_two_entry_points(gpu_device):
         assert torch.equal(topk, graph.topk) and torch.equal(deg, graph.deg)
         assert torch.equal(nbr.view(torch.int16), graph.nbr.view(torch.int16))
         assert torch.equal(terms2, terms)
-
-
-def test_matrix_core_backward_is_bitwise_reproducible(gpu_device):
-    """d_xlin, d_s_i, d_s_j of the matrix-core backward have no atomics and no order-dependent reductions: 300
-    launches on the same inputs (512 windows: every workgroup takes two) give the same bits — a stale read across
-    one of its ten barriers per window would show up here.  (d_bias is summed with float atomics across
-    workgroups, as in the row-gather kernel, and is only checked to rounding.)"""
-    from gdn_amd import ops
-    n, k, b, d = 127, 30, 512, 64
-    g = torch.Generator().manual_seed(11)
-    graph = ops.topk_graph(torch.randn((n, d), generator=g).to(gpu_device), k)
-    xlin = torch.randn((b * n, d), generator=g).to(gpu_device)
-    s_i, s_j = torch.randn((b * n,), generator=g).to(gpu_device), torch.randn((b * n,), generator=g).to(gpu_device)
-    bias = torch.zeros((d,), device=gpu_device)
-    d_z = (torch.randn((b * n, d), generator=g) * 1e-6).to(gpu_device)
-    _z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, graph, bias, b, want_alpha=True)
-    first = ops.attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph, b)
-    for _ in range(300):
-        again = ops.attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph, b)
-        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1]) and torch.equal(first[2], again[2])
-        np.testing.assert_allclose(again[3].cpu().numpy(), first[3].cpu().numpy(), rtol=1e-4, atol=1e-9)

@@ -142,3 +142,32 @@ def test_full_batch_configs_oracle_matches_reference(case):
     if m["k"] < m["n"]:
         assert torch.equal(r["learned_graph"], torch.from_numpy(data["learned_graph"]))
     np.testing.assert_allclose(r["out"].numpy(), data["eval_out"], atol=FP32_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_staged_float64_restatement_equals_the_op_faithful_oracle(case):
+    """tests/_grad_check.py::staged_f64 — the training step in the decomposition the HIP kernels use, in float64,
+    the checker of every gradient test — against gdn_oracle.forward (the op-faithful restatement the fixtures pin)
+    run in float64 on the fixture's train-mode inputs: loss and every parameter gradient to 1e-10 relative; and
+    against the gradients the REFERENCE produced in fp32 (fixture), to the fp32 level."""
+    from _grad_check import f64_leaves, oracle_step
+    data, p = load_golden(case)
+    m = meta(data)
+    x, y = torch.from_numpy(data["x"]), torch.from_numpy(data["y"])
+    mask, graph = torch.from_numpy(data["dropout_mask"]), torch.from_numpy(data["learned_graph"])
+    loss, grads, kink = oracle_step(p, x, y, graph, m["out_layer_num"], mask)
+    leaf = f64_leaves(p)
+    r = gdn_oracle.forward(leaf, x.double(), m["k"], m["out_layer_num"], training=True, dropout_mask=mask.double(),
+                           graph=graph)
+    ref_loss = torch.nn.functional.mse_loss(r["out"], y.double())
+    ref_loss.backward()
+    assert abs(loss - float(ref_loss.detach())) < 1e-12
+    for name, g in grads.items():
+        want = leaf[name].grad
+        top = float(want.abs().max())
+        if top < 1e-12:           # a bias in front of a train-mode BatchNorm: both sides hold float64 rounding noise
+            assert float(g.abs().max()) < 1e-12, name
+            continue
+        assert float((g - want).abs().max()) <= 1e-10 * top, name
+        np.testing.assert_allclose(g.numpy(), data["g/" + name].astype(np.float64), atol=5e-5, rtol=1e-3, err_msg=name)
+    assert kink > 2e-6          # no (Leaky)ReLU input of the fixture sits in the fp32 rounding band
