@@ -161,7 +161,7 @@ def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
     def launch(i):          # raw C-ABI call: host cost per launch stays below the kernel's duration
         s = (i % nslots) * batch
         _lib.call("gdn_forward_fused_plan", xs.data_ptr() + s * xstride, plan.data_ptr(), batch, N_SENSORS, WINDOW, DIM,
-                  TOPK, int(bf16), pred.data_ptr() + s * pstride, st)
+                  TOPK, int(bf16), pred.data_ptr() + s * pstride, None, st)
     for i in range(3):
         launch(i)
     mean_us, med_us = event_time_launches(launch, launches)

@@ -57,8 +57,14 @@ SIGNATURES = {
     "gdn_mlp_fwd": [_p, _p] + [_c_int] * 4 + [_p, _p],
     "gdn_fused_plan_bytes": [_c_int] * 5,
     "gdn_fused_plan_build": [_p] * 10 + [_c_int] * 5 + [_p, _p],
-    "gdn_forward_fused_plan": [_p, _p] + [_c_int] * 6 + [_p, _p],
-    "gdn_forward_fused_series_plan": [_p, _c_int, _c_int, _p] + [_c_int] * 5 + [_p, _p],
+    "gdn_forward_fused_plan": [_p, _p] + [_c_int] * 6 + [_p, _p, _p],
+    "gdn_forward_fused_series_plan": [_p, _c_int, _c_int, _p] + [_c_int] * 5 + [_p, _p, _p],
+    "gdn_fused_plan_limit_offset": [_c_int] * 5,
+    "gdn_forward_fused_gated": [_p] * 12 + [_c_int] * 5 + [_p, _p],
+    "gdn_forward_fused_series_gated": [_p, _p, _c_int, _c_int] + [_p] * 10 + [_c_int] * 5 + [_p, _p],
+    "gdn_project_fwd_wide": [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p],
+    "gdn_attn_aggregate_fwd_wide": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
+    "gdn_attn_aggregate_bwd_wide": [_p] * 8 + [_c_int] * 4 + [_p] * 6,
     "gdn_project_fwd_bf16": [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p],
     "gdn_attn_aggregate_fwd_bf16": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p],
     "gdn_head_fwd_bf16": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _p],
@@ -103,7 +109,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_longlong if name.endswith("_bytes") else _c_int
+        fn.restype = ctypes.c_longlong if name.endswith(("_bytes", "_offset")) else _c_int
     if lib.gdn_abi_version() != ABI_VERSION:
         raise GdnHipError(f"ABI mismatch: library {lib.gdn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -575,15 +575,16 @@ extern "C" int gdn_attn_aggregate_bwd_uses_reverse(int n, int d, int k) {
   return (d == 64 && !gdn_bwd_valu_forced() && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k)) ? 0 : 1;
 }
 
-extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
-                                      const float* s_i, const float* s_j, const uint16_t* nbr,
-                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
-                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
-                                      float* workspace, void* stream) {
+static int attn_aggregate_bwd_impl(const float* d_z, const float* xlin, const float* alpha,
+                                   const float* s_i, const float* s_j, const uint16_t* nbr,
+                                   const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                   int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                   float* workspace, void* stream, bool wide) {
+  const bool dense = !wide && !gdn_attn_aggregate_bwd_uses_reverse(n, d, k);
   if (!d_z || !xlin || !alpha || !s_i || !s_j || !nbr || !d_xlin || !d_si || !d_sj || !d_bias || !workspace ||
       batch <= 0 || n <= 0 || k <= 0)
     return GDN_ERR_ARG;
-  if ((!rent || !rlen) && gdn_attn_aggregate_bwd_uses_reverse(n, d, k)) return GDN_ERR_ARG;
+  if ((!rent || !rlen) && !dense) return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
   BwdPlan pl;
@@ -595,9 +596,9 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
   }
   hipStream_t st = (hipStream_t)stream;
   float* dpi_ws = workspace + bwd_bias_ws_floats(d);
-  const bool wide = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
+  const bool many_rows = n * (d / 64 > 0 ? d / 64 : 1) > 64;   // enough rows for 32 lane groups
   // matrix-core shapes: both halves of the backward as dense products (gdn_forward_dense.hip)
-  if (!gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
+  if (dense)
     return gdn_dense_attn_bwd(d_z, xlin, alpha, s_i, s_j, nbr, batch, n, k, d_xlin, d_si, d_sj, d_bias, workspace, st);
 #define GDN_BWD_NT(DD, NT, GL)                                                                        \
   {                                                                                                   \
@@ -609,7 +610,7 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
 #define GDN_BWD(DD)                                                   \
   case DD:                                                            \
     if (glb) GDN_BWD_NT(DD, 512, true)                                \
-    else if (wide) GDN_BWD_NT(DD, 512, false)                         \
+    else if (many_rows) GDN_BWD_NT(DD, 512, false)                         \
     else GDN_BWD_NT(DD, 256, false)                                   \
     break;
   switch (d) {
@@ -621,6 +622,24 @@ extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const
 #undef GDN_BWD
 #undef GDN_BWD_NT
   return gdn_launch_status();
+}
+
+extern "C" int gdn_attn_aggregate_bwd(const float* d_z, const float* xlin, const float* alpha,
+                                      const float* s_i, const float* s_j, const uint16_t* nbr,
+                                      const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                      int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                      float* workspace, void* stream) {
+  return attn_aggregate_bwd_impl(d_z, xlin, alpha, s_i, s_j, nbr, rent, rlen, batch, n, d, k, d_xlin, d_si, d_sj,
+                                 d_bias, workspace, stream, false);
+}
+// `_wide`: the row-gather backward at every shape (reverse lists required)
+extern "C" int gdn_attn_aggregate_bwd_wide(const float* d_z, const float* xlin, const float* alpha,
+                                           const float* s_i, const float* s_j, const uint16_t* nbr,
+                                           const uint32_t* rent, const int32_t* rlen, int batch, int n, int d,
+                                           int k, float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                           float* workspace, void* stream) {
+  return attn_aggregate_bwd_impl(d_z, xlin, alpha, s_i, s_j, nbr, rent, rlen, batch, n, d, k, d_xlin, d_si, d_sj,
+                                 d_bias, workspace, stream, true);
 }
 
 // 1 when every kernel of a training step (staged forward, this file's backward) takes the shape: what

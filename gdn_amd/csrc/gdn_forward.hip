@@ -141,6 +141,10 @@ struct Args {
   float* alpha;     // [BN, pitch] or null
   float* out;       // [BN]      (MODE_FUSED)
   int x_bf16;       // bf16 storage: x holds bfloat16 bits, the projected tile is rounded to bf16
+  // MODE_FUSED, optional: gate[0] = the range flag a preceding matrix-core launch may have set, gate[1] = a ticket.
+  // gate[0] == 0: every workgroup returns at once (the launch costs its dispatch only); otherwise the launch
+  // recomputes all windows in fp32 and the last workgroup to finish clears both words for the next call.
+  int* gate;
 };
 
 // x element idx of a window whose first element is `elems` past a.x, for either storage type
@@ -153,6 +157,21 @@ __device__ __forceinline__ float x_elem(const Args& a, const float* base, size_t
 __device__ __forceinline__ float round_to_bf16(float v) {   // round to nearest even, as torch's .bfloat16()
   const unsigned u = __float_as_uint(v);
   return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+}
+
+// End of a gated MODE_FUSED launch (Args::gate): every workgroup has read the flag by the time the last ticket is
+// drawn, so the workgroup that draws it clears flag and ticket for the next call.
+__device__ __forceinline__ void gate_release(const Args& a) {
+  if (!a.gate) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = (int)(gridDim.x * gridDim.y);
+    const int t = __hip_atomic_fetch_add(a.gate + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == total - 1) {
+      __hip_atomic_store(a.gate + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.gate, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ projection phase
@@ -777,6 +796,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
   extern __shared__ float4 smem_f4[];
   float* smem = reinterpret_cast<float*>(smem_f4);
   const int tid = threadIdx.x, nth = blockDim.x;
+  if constexpr (MODE == MODE_FUSED) {
+    if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // wave uniform
+  }
 
   // once per workgroup: neighbour lists + degrees into LDS; sentinel row n of the tile = 0 and
   // s_j[n] = -inf (the padding slots of every neighbour list point there)
@@ -867,6 +889,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
     if constexpr (PROJ >= 2) {
       static_assert(D >= 32 || PROJ < 2, "MFMA projection needs d >= 32");
       window_loop_mfma<D, MODE, (PROJ == 4 ? 32 : 16), (PROJ == 2 ? 8 : 16), LST>(pl, a, smem);
+      if constexpr (MODE == MODE_FUSED) gate_release(a);
       return;
     }
     float* xs = smem + pl.off_xs;
@@ -916,6 +939,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
       }
     }
   }
+  if constexpr (MODE == MODE_FUSED) gate_release(a);
 }
 
 // ------------------------------------------------------------------ head (staged eval path)
@@ -1132,10 +1156,10 @@ int gdn_forward_staged_ok(int n, int w, int d, int k) {
          make_plan(MODE_ATTN, 1, n, 0, d, k, &pl, &threads) == GDN_OK;
 }
 
-extern "C" int gdn_project_fwd(const float* x, const float* lin_w, const float* node_terms, int batch,
-                               int n, int w, int d, float* xlin, float* s_i, float* s_j, void* stream) {
+static int project_fwd_impl(const float* x, const float* lin_w, const float* node_terms, int batch,
+                            int n, int w, int d, float* xlin, float* s_i, float* s_j, void* stream, bool wide) {
   if (!x || !lin_w || !node_terms || !xlin || !s_i || !s_j) return GDN_ERR_ARG;
-  if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, w, d, 1))
+  if (!wide && batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, w, d, 1))
     return gdn_dense_project(x, 0, lin_w, node_terms, batch, n, w, d, xlin, s_i, s_j, (hipStream_t)stream);
   Plan pl; int threads;
   const int rc = make_plan(MODE_PROJECT, batch, n, w, d, 0, &pl, &threads);
@@ -1146,12 +1170,22 @@ extern "C" int gdn_project_fwd(const float* x, const float* lin_w, const float* 
   return dispatch_window<MODE_PROJECT>(pl, a, threads, (hipStream_t)stream);
 }
 
-extern "C" int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const float* s_j,
-                                      const uint16_t* nbr, const int32_t* deg, const float* bias,
-                                      int batch, int n, int d, int k, float* z, float* alpha,
-                                      void* stream) {
+extern "C" int gdn_project_fwd(const float* x, const float* lin_w, const float* node_terms, int batch,
+                               int n, int w, int d, float* xlin, float* s_i, float* s_j, void* stream) {
+  return project_fwd_impl(x, lin_w, node_terms, batch, n, w, d, xlin, s_i, s_j, stream, false);
+}
+// `_wide`: the fp32 row-gather kernels at every shape — inputs beyond the range of the 16-bit operand terms
+extern "C" int gdn_project_fwd_wide(const float* x, const float* lin_w, const float* node_terms, int batch,
+                                    int n, int w, int d, float* xlin, float* s_i, float* s_j, void* stream) {
+  return project_fwd_impl(x, lin_w, node_terms, batch, n, w, d, xlin, s_i, s_j, stream, true);
+}
+
+static int attn_aggregate_fwd_impl(const float* xlin, const float* s_i, const float* s_j,
+                                   const uint16_t* nbr, const int32_t* deg, const float* bias,
+                                   int batch, int n, int d, int k, float* z, float* alpha,
+                                   void* stream, bool wide) {
   if (!xlin || !s_i || !s_j || !nbr || !deg || !bias || !z) return GDN_ERR_ARG;
-  if (batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k))
+  if (!wide && batch > 0 && gdn_use_dense_path() && gdn_dense_supported(n, 1, d, k))
     return gdn_dense_attn_aggregate(xlin, 0, s_i, s_j, nbr, bias, batch, n, d, k, z, alpha, (hipStream_t)stream);
   Plan pl; int threads;
   const int rc = make_plan(MODE_ATTN, batch, n, 0, d, k, &pl, &threads);
@@ -1162,16 +1196,31 @@ extern "C" int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const
   return dispatch_window<MODE_ATTN>(pl, a, threads, (hipStream_t)stream);
 }
 
+extern "C" int gdn_attn_aggregate_fwd(const float* xlin, const float* s_i, const float* s_j,
+                                      const uint16_t* nbr, const int32_t* deg, const float* bias,
+                                      int batch, int n, int d, int k, float* z, float* alpha,
+                                      void* stream) {
+  return attn_aggregate_fwd_impl(xlin, s_i, s_j, nbr, deg, bias, batch, n, d, k, z, alpha, stream, false);
+}
+extern "C" int gdn_attn_aggregate_fwd_wide(const float* xlin, const float* s_i, const float* s_j,
+                                           const uint16_t* nbr, const int32_t* deg, const float* bias,
+                                           int batch, int n, int d, int k, float* z, float* alpha,
+                                           void* stream) {
+  return attn_aggregate_fwd_impl(xlin, s_i, s_j, nbr, deg, bias, batch, n, d, k, z, alpha, stream, true);
+}
+
 namespace {
 // sparse-gather kernel for the shapes the dense kernels do not cover (x_bf16: bf16 storage of x and xlin)
 int fused_gather(const void* x, int x_bf16, const float* lin_w, const float* node_terms, const uint16_t* nbr,
                  const int32_t* deg, const float* gnn_bias, const float* emb, const float* bn1_affine,
                  const float* bn2_affine, const float* out_w, const float* out_b, int batch, int n, int w,
-                 int d, int k, float* out, void* stream) {
+                 int d, int k, float* out, void* stream, int* gate = nullptr) {
   Plan pl; int threads;
   const int rc = make_plan(MODE_FUSED, batch, n, w, d, k, &pl, &threads);
   if (rc != GDN_OK) return rc;
+  if (gate && pl.nslices > 1) return GDN_ERR_UNSUPPORTED;   // (the sliced form clears `out` first: not gateable)
   Args a = {};
+  a.gate = gate;
   a.x = static_cast<const float*>(x); a.x_bf16 = x_bf16; a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.deg = deg;
   a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;
   a.out_w = out_w; a.out_b = out_b; a.out = out;
@@ -1197,6 +1246,41 @@ extern "C" int gdn_forward_fused(const float* x, const float* lin_w, const float
                       batch, n, w, d, k, out, stream);
 }
 
+// The row-gather (fp32 VALU) fused forward, optionally GATED on a range guard (include/gdn_hip.h "range guard"):
+// guard == null runs it unconditionally (inputs known to exceed the 16-bit operand range); otherwise the launch
+// does nothing unless guard[0] != 0, recomputes every window in fp32 when it is, and leaves guard[0..1] = 0.
+extern "C" int gdn_forward_fused_gated(int* guard, const float* x, const float* lin_w, const float* node_terms,
+                                       const uint16_t* nbr, const int32_t* deg, const float* gnn_bias,
+                                       const float* emb, const float* bn1_affine, const float* bn2_affine,
+                                       const float* out_w, const float* out_b, int batch, int n, int w, int d,
+                                       int k, float* out, void* stream) {
+  if (!x || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine ||
+      !bn2_affine || !out_w || !out_b || !out)
+    return GDN_ERR_ARG;
+  return fused_gather(x, 0, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine, bn2_affine, out_w, out_b,
+                      batch, n, w, d, k, out, stream, guard);
+}
+
+static int fused_gather_series(const float* series, int series_len, int first, const float* lin_w,
+                               const float* node_terms, const uint16_t* nbr, const int32_t* deg,
+                               const float* gnn_bias, const float* emb, const float* bn1_affine,
+                               const float* bn2_affine, const float* out_w, const float* out_b,
+                               int batch, int n, int w, int d, int k, float* out, void* stream, int* gate);
+
+extern "C" int gdn_forward_fused_series_gated(int* guard, const float* series, int series_len, int first,
+                                              const float* lin_w, const float* node_terms, const uint16_t* nbr,
+                                              const int32_t* deg, const float* gnn_bias, const float* emb,
+                                              const float* bn1_affine, const float* bn2_affine, const float* out_w,
+                                              const float* out_b, int batch, int n, int w, int d, int k, float* out,
+                                              void* stream) {
+  if (!series || !lin_w || !node_terms || !nbr || !deg || !gnn_bias || !emb || !bn1_affine ||
+      !bn2_affine || !out_w || !out_b || !out || series_len <= 0 || first < 0)
+    return GDN_ERR_ARG;
+  if ((long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;
+  return fused_gather_series(series, series_len, first, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine,
+                             bn2_affine, out_w, out_b, batch, n, w, d, k, out, stream, guard);
+}
+
 extern "C" int gdn_forward_fused_series(const float* series, int series_len, int first, const float* lin_w,
                                         const float* node_terms, const uint16_t* nbr, const int32_t* deg,
                                         const float* gnn_bias, const float* emb, const float* bn1_affine,
@@ -1209,11 +1293,22 @@ extern "C" int gdn_forward_fused_series(const float* series, int series_len, int
   if (batch > 0 && gdn_use_dense_path() && gdn_dense_fused_supported(n, w, d, k))
     return gdn_dense_forward_fused(series, 0, series_len, first, lin_w, node_terms, nbr, gnn_bias, emb, bn1_affine,
                                    bn2_affine, out_w, out_b, batch, n, w, d, k, out, (hipStream_t)stream);
+  return fused_gather_series(series, series_len, first, lin_w, node_terms, nbr, deg, gnn_bias, emb, bn1_affine,
+                             bn2_affine, out_w, out_b, batch, n, w, d, k, out, stream, nullptr);
+}
+
+static int fused_gather_series(const float* series, int series_len, int first, const float* lin_w,
+                               const float* node_terms, const uint16_t* nbr, const int32_t* deg,
+                               const float* gnn_bias, const float* emb, const float* bn1_affine,
+                               const float* bn2_affine, const float* out_w, const float* out_b,
+                               int batch, int n, int w, int d, int k, float* out, void* stream, int* gate) {
   Plan pl; int threads;
   const int rc = make_plan(MODE_FUSED, batch, n, w, d, k, &pl, &threads);
   if (rc != GDN_OK) return rc;
   if (!pl.mfma) return GDN_ERR_UNSUPPORTED;   // series addressing lives in the MFMA-projection variants
+  if (gate && pl.nslices > 1) return GDN_ERR_UNSUPPORTED;
   Args a = {};
+  a.gate = gate;
   a.x = series; a.series_len = series_len; a.series_first = first;
   a.lin_w = lin_w; a.node_terms = node_terms; a.nbr = nbr; a.deg = deg;
   a.gnn_bias = gnn_bias; a.emb = emb; a.bn1 = bn1_affine; a.bn2 = bn2_affine;

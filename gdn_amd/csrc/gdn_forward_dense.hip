@@ -63,7 +63,16 @@ struct Fmt<FMT_F16> {
   // round to nearest even (v_cvt_pk_f16_f32 or two v_cvt_f16_f32).  NOT inline asm: the result is an MFMA
   // operand, and hipcc inserts the VALU-write -> MFMA-read wait states only for instructions it can see (an
   // asm conversion directly in front of the product fed it stale registers: wrong first column block)
+  // The two EMPTY asm statements (nothing executes in them) pin a and b as MATERIALISED fp32 values.  Without them
+  // a product feeding the conversion — pk(x * s, ...) after inlining — is contracted into one v_fma_mixlo_f16,
+  // which rounds the EXACT product to f16, while res0 / res1 subtract from the fp32-ROUNDED product: where the
+  // two roundings disagree (a double-rounding case, one value in ~2^13) the compiler had materialised two
+  // different "hi" values, hi + lo missed the value by a whole f16 ulp (2^-11 relative) and the forward was off by
+  // 1.2e-6 instead of 3e-8 (4 of the 8192 lin' operand halves of a plan; found in round 3 by comparing plans
+  // built by two compilations of the same source, tools/_diag/plan_words_probe.py).
   static __device__ __forceinline__ unsigned pk(float a, float b) {
+    asm("" : "+v"(a));
+    asm("" : "+v"(b));
     const h2 p = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, p);
   }
@@ -91,6 +100,8 @@ struct Fmt<FMT_F16> {
 template <>
 struct Fmt<FMT_BF16> {
   static __device__ __forceinline__ unsigned pk(float a, float b) {
+    asm("" : "+v"(a));                         // (materialised fp32 inputs: see Fmt<FMT_F16>::pk)
+    asm("" : "+v"(b));
     const b2 p = {(__bf16)a, (__bf16)b};       // v_cvt_pk_bf16_f32, round to nearest even (not asm: see above)
     return __builtin_bit_cast(unsigned, p);
   }
@@ -180,6 +191,10 @@ struct DArgs {
   const float* key_gt;      // [B, n] ground truth
   double* keys;             // [n, key_pitch]
   int key_pitch;
+  // optional range guard (fp32 storage only): set to 1 when an input value lies outside the range the 16-bit
+  // operand terms represent (|x| >= the plan's x limit, or NaN) — the launch's results are then not to be used
+  // and the caller's gated row-gather launch (gdn_forward_fused_gated) recomputes them in fp32
+  int* range_flag;
 };
 
 __device__ __forceinline__ float lds_f32(const char* smem, int byte_off) {
@@ -273,7 +288,8 @@ struct LaneConsts {
   float out_b;
   static constexpr int WORDS = 2 * SL + 4 * (DC * WK * C::NTL + WK * C::NTL) + DC + 16 * DC + 1;
   static constexpr int TABLE_WORDS = 4 * 32 * DC + 3 * C::ROWS;     // [ec | cs] as they sit in LDS
-  static constexpr size_t PLAN_BYTES = ((size_t)TABLE_WORDS + (size_t)WORDS * C::THREADS) * 4;
+  static constexpr size_t LIMIT_WORD = (size_t)TABLE_WORDS + (size_t)WORDS * C::THREADS;   // the x limit (float)
+  static constexpr size_t PLAN_BYTES = (LIMIT_WORD + 1) * 4;
 
   // visits every 32-bit word in a fixed order: f(word index, reference to the word as unsigned)
   template <class Fn>
@@ -398,6 +414,35 @@ __device__ __forceinline__ void compute_tables(const DArgs& a, float* dst) {
   }
 }
 
+// Largest |x| the fp32-storage kernel represents (the "x limit" of a plan).  x itself becomes two f16 terms
+// (|x| < 65504), and so does the BatchNorm-folded projected tile times 2^3: |tile| <= max|x| * L1 + C with
+// L1 = max_c sum_w |lin'[c, w]| and C = max_c |C-in[c]| (both carry the 2^3).  limit = min(60000, (60000 - C) / L1);
+// 0 when C alone is out of range (every launch is then flagged).  bf16 storage: x is one exact bf16 term with
+// fp32's exponent range, the tile is rounded to bf16: no limit (+inf).
+template <int NT, int DC, int FMT>
+__device__ __forceinline__ float compute_xlimit(const DArgs& a) {
+  if constexpr (FMT != FMT_F16) return INFINITY;
+  __shared__ unsigned m_l1, m_c;
+  const int tid = threadIdx.x, d = 32 * DC;
+  if (tid == 0) { m_l1 = 0u; m_c = 0u; }
+  __syncthreads();
+  for (int c = tid; c < d; c += 64 * NT) {
+    const float sc = a.bn1[c] * GDN_F16_X_SCALE;
+    float l1 = 0.f;
+    for (int q = 0; q < a.w; ++q) l1 += fabsf(a.lin_w[c * a.w + q] * sc);
+    const float cin = fabsf(fmaf(a.gnn_bias[c], a.bn1[c], a.bn1[d + c]) * GDN_F16_X_SCALE);
+    // non-negative floats order like their bits; NaN / inf parameters compare as huge: limit 0
+    atomicMax(&m_l1, __float_as_uint(l1));
+    atomicMax(&m_c, __float_as_uint(cin));
+  }
+  __syncthreads();
+  const float l1 = __uint_as_float(m_l1), cmax = __uint_as_float(m_c);
+  float lim = 60000.f;
+  if (!(cmax < 60000.f) || !(l1 < 3.0e38f)) lim = 0.f;
+  else if (l1 > 0.f) lim = fminf(lim, (60000.f - cmax) / l1);
+  return lim;
+}
+
 // The plan also ORDERS each lane's list slots.  A lane may visit its SL slots in any order (softmax and the
 // scatter do not care), and the order decides which LDS banks the 32 lanes of a half-wave hit together in
 // step q: the s_j gather (ds_read_b32) and, twice per window, the scatter into the dense alpha image
@@ -450,6 +495,8 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_plan_kernel(const DArgs a, 
   compute_tables<NT, DC>(a, reinterpret_cast<float*>(plan));
   unsigned* lanes = plan + K::TABLE_WORDS;
   k.each_word([&](int i, unsigned& wd) { lanes[i * T + threadIdx.x] = wd; });
+  const float xlim = compute_xlimit<NT, DC, FMT>(a);
+  if (threadIdx.x == 0) plan[K::LIMIT_WORD] = __float_as_uint(xlim);
 }
 
 #ifdef GDN_DENSE_EXTRA_DC   // d = 128: one workgroup per CU and the whole 512-register file per wave (the default
@@ -478,15 +525,21 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
   }
   // per-launch constants: from the plan, or computed here (gdn_forward_fused without a plan)
   LaneConsts<NT, DC, WK, SL, FMT> k;
+  float xlim = INFINITY;                       // range guard (fp32 storage): see compute_xlimit
   if (a.plan) {
     const unsigned* lanes = a.plan + LaneConsts<NT, DC, WK, SL, FMT>::TABLE_WORDS;
     k.each_word([&](int i, unsigned& wd) { wd = lanes[i * C::THREADS + tid]; });
     unsigned* tab = reinterpret_cast<unsigned*>(smem + C::OFF_EC);
     for (int t = tid; t < LaneConsts<NT, DC, WK, SL, FMT>::TABLE_WORDS; t += C::THREADS) tab[t] = a.plan[t];
+    if constexpr (FMT == FMT_F16)
+      if (a.range_flag) xlim = __uint_as_float(a.plan[LaneConsts<NT, DC, WK, SL, FMT>::LIMIT_WORD]);
   } else {
-    compute_lane_consts(a, k);
+    compute_lane_consts(a, k);     // (no plan, no x limit: the range guard is a feature of planned launches)
     compute_tables<NT, DC>(a, reinterpret_cast<float*>(smem + C::OFF_EC));
   }
+  // out-of-range lanes, as a wave-uniform mask in scalar registers (the kernel sits AT its 256-VGPR budget: a
+  // per-lane flag cost 20 more spilled registers and 9 % of the launch)
+  unsigned long long out_of_range = 0ull;
   const int si_off = C::OFF_SI + (32 * wv + (lane >> 1)) * 4;
   const int cs_off = C::OFF_CS + (min(l32, 2) * C::ROWS + 32 * wv + 4 * h) * 4;   // + 32 (r >> 2): 4 rows
   const int tgt = 32 * wv + l32;
@@ -535,8 +588,13 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
 
   for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
 #pragma unroll
-    for (int u = 0; u < C::XU; ++u)
-      *reinterpret_cast<float*>(smem + xst_off + u * (RS * C::XP * 4)) = xok[u] ? xr[u] : 0.f;
+    for (int u = 0; u < C::XU; ++u) {
+      const float xv = xok[u] ? xr[u] : 0.f;
+      *reinterpret_cast<float*>(smem + xst_off + u * (RS * C::XP * 4)) = xv;
+#ifndef GDN_NO_GUARD
+      if constexpr (FMT == FMT_F16) out_of_range |= __builtin_amdgcn_ballot_w64(!(fabsf(xv) < xlim));   // (NaN too)
+#endif
+    }
     if (b == (int)blockIdx.x) { GDN_STAMP(3) }
     __syncthreads();                                           // B1: x tile of window b visible
     load_window(min(b + (int)gridDim.x, a.batch - 1));         // lands under the math (last round: re-read)
@@ -694,6 +752,8 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
     }
     if (b == (int)blockIdx.x) { GDN_STAMP(9) }
   }
+  if constexpr (FMT == FMT_F16)
+    if (a.range_flag && out_of_range != 0ull && lane == 0) a.range_flag[0] = 1;     // (same value from every writer)
   GDN_STAMP(10)
 }
 
@@ -1702,7 +1762,7 @@ extern "C" int gdn_fused_plan_build(const float* lin_w, const float* node_terms,
 
 static int fused_with_plan(const void* x, int series_len, int first, const void* plan, int batch, int n, int w,
                            int d, int k, int bf16_storage, float* out, void* stream, const float* key_gt = nullptr,
-                           double* keys = nullptr, int key_pitch = 0) {
+                           double* keys = nullptr, int key_pitch = 0, int* range_guard = nullptr) {
   if (!x || !plan || !out) return GDN_ERR_ARG;
   if (batch <= 0 || n <= 0) return GDN_ERR_ARG;
   if (keys && (!key_gt || key_pitch < batch)) return GDN_ERR_ARG;
@@ -1712,18 +1772,27 @@ static int fused_with_plan(const void* x, int series_len, int first, const void*
   a.batch = batch; a.n = n; a.w = w; a.pitch = gdn_nbr_pitch(k); a.d = d;
   a.out = out; a.plan = reinterpret_cast<const unsigned*>(plan);
   a.key_gt = key_gt; a.keys = keys; a.key_pitch = key_pitch;
+  a.range_flag = bf16_storage ? nullptr : range_guard;
   return fused_dispatch(DOP_LAUNCH, a, bf16_storage, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int gdn_forward_fused_plan(const void* x, const void* plan, int batch, int n, int w, int d, int k,
-                                      int bf16_storage, float* out, void* stream) {
-  return fused_with_plan(x, 0, 0, plan, batch, n, w, d, k, bf16_storage, out, stream);
+                                      int bf16_storage, float* out, int* range_guard, void* stream) {
+  return fused_with_plan(x, 0, 0, plan, batch, n, w, d, k, bf16_storage, out, stream, nullptr, nullptr, 0, range_guard);
 }
 
 extern "C" int gdn_forward_fused_series_plan(const float* series, int series_len, int first, const void* plan,
-                                             int batch, int n, int w, int d, int k, float* out, void* stream) {
+                                             int batch, int n, int w, int d, int k, float* out, int* range_guard,
+                                             void* stream) {
   if (series_len <= 0 || first < 0 || (long long)first + batch - 1 + w > series_len) return GDN_ERR_ARG;
-  return fused_with_plan(series, series_len, first, plan, batch, n, w, d, k, 0, out, stream);
+  return fused_with_plan(series, series_len, first, plan, batch, n, w, d, k, 0, out, stream, nullptr, nullptr, 0,
+                         range_guard);
+}
+
+// the x limit of a plan, as a byte offset into it (the host reads one float there, once)
+extern "C" long long gdn_fused_plan_limit_offset(int n, int w, int d, int k, int bf16_storage) {
+  const long long bytes = gdn_fused_plan_bytes(n, w, d, k, bf16_storage);
+  return bytes > 0 ? bytes - 4 : -1;
 }
 
 // The same two launches, also leaving the scoring keys |out - gt| (float64, [n, key_pitch], key_pitch >= batch)

@@ -26,6 +26,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {
+  // (a, b pinned as materialised fp32 values by two EMPTY asm statements: a product feeding the conversion is
+  // otherwise contracted into v_fma_mixlo_f16 — f16 of the EXACT product — while the residual is taken against the
+  // fp32-rounded one; see Fmt<FMT_F16>::pk in gdn_forward_dense.hip)
+  asm("" : "+v"(a));
+  asm("" : "+v"(b));
   const h2 p = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, p);
 }
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(256) void mlp_plan_layer_kernel(const float* __rest
       const float scale = bn_w[n] / sqrtf(bn_var[n] + eps);
       v = w[(size_t)n * k_in + k] * scale;
     }
+    asm("" : "+v"(v));          // the fp32-ROUNDED product is what gets split (see pk_f16)
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     _Float16* slab = reinterpret_cast<_Float16*>(base + (size_t)ks * mlp_slab_bytes(g));

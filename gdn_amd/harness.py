@@ -65,13 +65,23 @@ def train(model=None, save_path="", config=None, train_dataloader=None, val_data
     if not use_graph:
         optimizer = torch.optim.Adam(model.parameters(), lr=0.001, weight_decay=config.get("decay", 0))
     losses, min_loss, stale = [], 1e8, 0
+    # Range of the training inputs (include/gdn_hip.h "range guard"): decided ONCE — config["wide"] when the caller
+    # knows (python -m gdn_amd.main looks at its resident series), else from the first batch — and pinned on the
+    # model for the whole run: no per-step host check, and the captured step needs the answer before the capture
+    range_before = getattr(model, "operand_range", "auto")
+    wide = config.get("wide", None)
     for _epoch in range(config.get("epoch", 1)):
         model.train()
         epoch_losses = []
         for x, labels, _attack, edge_index in train_dataloader:
             x, labels = x.float().to(device), labels.float().to(device)
+            if wide is None and range_before == "auto":
+                wide = model.input_exceeds_limit(x, margin=16.0)      # (the weights move during training)
+            if range_before == "auto":
+                model.operand_range = "wide" if wide else "narrow"
             if use_graph and graphed is None:
-                graphed = GraphedTrainStep(model, x.shape[0], lr=0.001, weight_decay=config.get("decay", 0))
+                graphed = GraphedTrainStep(model, x.shape[0], lr=0.001, weight_decay=config.get("decay", 0),
+                                           wide=model.operand_range == "wide")
                 optimizer = graphed.optimizer
             if graphed is not None and x.shape[0] == graphed.x.shape[0]:
                 graphed.x.copy_(x)
@@ -89,6 +99,7 @@ def train(model=None, save_path="", config=None, train_dataloader=None, val_data
         losses.extend(step_losses)
         acc = float(sum(step_losses))
         if val_dataloader is not None:
+            model.operand_range = range_before          # validation data: its own range (eval guard)
             val_loss, _ = test(model, val_dataloader, device)
             if val_loss < min_loss:
                 if save_path:
@@ -102,6 +113,7 @@ def train(model=None, save_path="", config=None, train_dataloader=None, val_data
             if save_path:
                 torch.save(model.state_dict(), save_path)
             min_loss = acc
+    model.operand_range = range_before
     return losses
 
 
@@ -323,6 +335,7 @@ class ShardedEvaluator:
                     for which in (0, 1)]
         self.halo_idx = torch.tensor(halo_idx, dtype=torch.int64, device=dev)
         self.forward = forward if forward is not None else self._hip_forward
+        self._wide = None
         # per-step buffers of the scoring kernels, allocated once (backends without the hooks allocate per call)
         self._sel_ws = self._sel_out = self._anomaly = None
         if hasattr(backend, "select_workspace") and self.n_mine:
@@ -335,7 +348,11 @@ class ShardedEvaluator:
         self._halo = torch.empty((2, 3, n), dtype=torch.float32, device=dev)
 
     def _hip_forward(self, start, stop):
-        self.model.forward_into(self.x[start:stop], self.pred[start:stop])
+        if self._wide is None:      # range of the resident shard, looked at once
+            m = self.model
+            self._wide = (m.operand_range == "wide" and self.x.dtype != torch.bfloat16) or (
+                m.operand_range == "auto" and m.input_exceeds_limit(self.x))
+        self.model.forward_into(self.x[start:stop], self.pred[start:stop], wide=self._wide)
 
     def step(self):
         works = []
@@ -393,6 +410,11 @@ class SeriesEvaluator:
         assert y_all.is_cuda and (x_all if x_all is not None else series).is_cuda
         self.series = series
         self.model, self.x, self.y, self.batch = model.eval(), x_all, y_all, batch * max(1, coalesce)
+        # range of the resident data, looked at ONCE (include/gdn_hip.h "range guard"): beyond the 16-bit operand
+        # range of the matrix-core kernels the whole evaluator runs on the fp32 row-gather kernels
+        src0 = series if series is not None else x_all
+        self.wide = (model.operand_range == "wide" and src0.dtype != torch.bfloat16) or (
+            model.operand_range == "auto" and model.out_layer_num == 1 and model.input_exceeds_limit(src0))
         self.logical_batch, self.coalesce = batch, max(1, coalesce)
         self.t, self.n = y_all.shape
         dev = y_all.device
@@ -420,7 +442,7 @@ class SeriesEvaluator:
         # constants and the plan are built (when stale) HERE, on the caller's stream, before the fork: built
         # lazily inside the first side-stream launch, the launches on the other side streams would read them
         # unordered (first eager step after a parameter update: garbage in some windows)
-        if m.out_layer_num == 1 and not m.training:
+        if m.out_layer_num == 1 and not m.training and not self.wide:
             src = self.series if self.series is not None else self.x
             m._plan(m._constants(), src.dtype == torch.bfloat16)
         spans = [(s, min(self.t, s + self.batch)) for s in range(0, self.t, self.batch)]
@@ -430,10 +452,10 @@ class SeriesEvaluator:
             return (self.y[s:e], self.ws.data_ptr() + 8 * s, self.t) if with_keys else None
         if self.series is not None:
             def launch(s, e):
-                m.forward_series(self.series, s, e - s, out=self.pred[s:e], keys=keys(s, e))
+                m.forward_series(self.series, s, e - s, out=self.pred[s:e], keys=keys(s, e), wide=self.wide)
         else:
             def launch(s, e):
-                m.forward_into(self.x[s:e], self.pred[s:e], keys=keys(s, e))
+                m.forward_into(self.x[s:e], self.pred[s:e], keys=keys(s, e), wide=self.wide)
         if len(self.side) < 2:
             for s, e in spans:
                 launch(s, e)
@@ -466,7 +488,7 @@ class SeriesEvaluator:
 
     def _launch_all(self):
         src = self.series if self.series is not None else self.x
-        fuse = self.fuse_keys and self.model.fused_keys_supported(src.dtype == torch.bfloat16)
+        fuse = self.fuse_keys and not self.wide and self.model.fused_keys_supported(src.dtype == torch.bfloat16)
         self._launch_forward(with_keys=fuse)
         self._launch_score(have_keys=fuse)
 
@@ -529,7 +551,8 @@ class AutogradTrainStep:
     `loss` (a device scalar) whenever convenient."""
 
     def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
-                 split: bool | None = None):
+                 split: bool | None = None, wide: bool = False):
+        self.wide = bool(wide)
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("GraphedTrainStep needs the model on a HIP device")
@@ -556,6 +579,7 @@ class AutogradTrainStep:
     # the two halves of a step; `loss` is written in place so it survives replays
     def _forward_backward(self):
         self.optimizer.zero_grad(set_to_none=True)      # backward then writes fresh gradients: no fill, no add
+        self.model.operand_range = "wide" if self.wide else "narrow"      # no host check inside a captured step
         out = self.model(self.x, None)
         if self._torch_mse:     # diagnostic (tools/probe_mse_replay.py): the round-1 form with torch's reduction
             loss = F.mse_loss(out, self.y, reduction="mean")
@@ -727,9 +751,13 @@ class NativeTrainStep:
         return model.out_layer_num == 1 or ops.mlp_train_supported(model.out_layer, model.embedding.weight.shape[1], 2)
 
     def __init__(self, model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
-                 split: bool | None = None, seed: int | None = None):
+                 split: bool | None = None, seed: int | None = None, wide: bool = False):
         from . import _lib
         self._lib = _lib
+        # inputs beyond the 16-bit operand range of the matrix-core kernels: the `_wide` (fp32 row-gather) entry
+        # points throughout, decided by the caller from its data (harness.train: first batch / config["wide"])
+        self.wide = bool(wide)
+        self._sfx = "_wide" if self.wide else ""
         self.model = model.train()
         dev = next(model.parameters()).device
         self.lr, self.wd = float(lr), float(weight_decay)
@@ -748,7 +776,9 @@ class NativeTrainStep:
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # torch's seeded generator picks the stream
+            # derived from torch's seed WITHOUT drawing from the global generator: the loaders' shuffle stream stays
+            # the reference's (main.py:221-228 seeds, main.py:128-148 draws)
+            seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & (2 ** 62 - 1)
         self.state = torch.tensor([seed, 0], dtype=torch.int64, device=dev)     # {dropout seed, steps taken}
         self.optimizer = _FlatAdam(self)
 
@@ -794,7 +824,7 @@ class NativeTrainStep:
                 act=torch.empty((bn_rows, d), **f32), d_act=torch.empty((bn_rows, d), **f32),
                 mlp_saved=torch.empty((lib.gdn_mlp_train_saved_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev),
                 mlp_ws=torch.empty((lib.gdn_mlp_train_workspace_bytes(bn_rows, d, h, layers),), dtype=torch.uint8, device=dev))
-        self._need_reverse = bool(lib.gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
+        self._need_reverse = self.wide or bool(lib.gdn_attn_aggregate_bwd_uses_reverse(n, d, k))
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self._fork = os.environ.get("GDN_TRAIN_FORK", "0") == "1"
         # GDN_FUSE_MSE=1: loss + d_out from the head's last forward pass (gdn_head_train_fwd_rng_mse) instead of
@@ -842,8 +872,8 @@ class NativeTrainStep:
             s2 = side.cuda_stream
             call("gdn_node_terms", P(g + "lin.weight"), P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"),
                  P("embedding.weight"), n, d, w, pt["terms"], s2)
-            call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
-                 pt["s_j"], s2)
+            call("gdn_project_fwd" + self._sfx, self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"],
+                 pt["s_i"], pt["s_j"], s2)
             call("gdn_topk_graph", P("embedding.weight"), n, d, k, pt["topk"], pt["nbr"], pt["deg"], None, st)
             side2.wait_stream(main)
             call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], side2.cuda_stream)
@@ -855,9 +885,9 @@ class NativeTrainStep:
                  P(g + "att_i"), P(g + "att_j"), P(g + "att_em_i"), P(g + "att_em_j"), w, pt["terms"], st)
             if self._need_reverse:       # only the row-gather backward reads the reverse lists
                 call("gdn_graph_reverse", pt["nbr"], pt["deg"], n, k, pt["rent"], pt["rlen"], st)
-            call("gdn_project_fwd", self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"], pt["s_i"],
-                 pt["s_j"], st)
-        call("gdn_attn_aggregate_fwd", pt["xlin"], pt["s_i"], pt["s_j"], pt["nbr"], pt["deg"], P(g + "bias"), b, n, d, k,
+            call("gdn_project_fwd" + self._sfx, self.x.data_ptr(), P(g + "lin.weight"), pt["terms"], b, n, w, d, pt["xlin"],
+                 pt["s_i"], pt["s_j"], st)
+        call("gdn_attn_aggregate_fwd" + self._sfx, pt["xlin"], pt["s_i"], pt["s_j"], pt["nbr"], pt["deg"], P(g + "bias"), b, n, d, k,
              pt["z"], pt["alpha"], st)
         m1, rm1, rv1, nb1 = self._bn_run(bn1)
         m2, rm2, rv2, nb2 = self._bn_run(bn2)
@@ -902,7 +932,7 @@ class NativeTrainStep:
             call("gdn_head_train_bwd_act", pt["d_act"], pt["z"], P("embedding.weight"), *bnp, None, None, 1.0, rng,
                  p_drop, pt["stats"], b, n, d, *eps, pt["head_ws"], pt["d_z"], G("embedding.weight"), *bng, 1, st)
         main.wait_stream(side2)                      # reverse lists
-        call("gdn_attn_aggregate_bwd", pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
+        call("gdn_attn_aggregate_bwd" + self._sfx, pt["d_z"], pt["xlin"], pt["alpha"], pt["s_i"], pt["s_j"], pt["nbr"], pt["rent"],
              pt["rlen"], b, n, d, k, pt["d_xlin"], pt["d_si"], pt["d_sj"], G(g + "bias"), pt["bwd_ws"], st)
         if self._mlp is None:
             # partial rows only; their reduction and the head's finishing reduction share ONE launch
@@ -978,11 +1008,16 @@ class NativeTrainStep:
 
 
 def GraphedTrainStep(model, batch: int, lr: float = 1e-3, weight_decay: float = 0.0, use_graph: bool = True,
-                     split: bool | None = None, native: bool | None = None):
-    """The captured training step: `NativeTrainStep` when the model allows it (out_layer_num == 1, plain
-    nn.Dropout), else `AutogradTrainStep`.  `native=False` forces the autograd form."""
+                     split: bool | None = None, native: bool | None = None, wide: bool | None = None):
+    """The captured training step: `NativeTrainStep` when the model and its shape allow it (plain nn.Dropout, an
+    OutLayer and a sensor count the training kernels take), else `AutogradTrainStep`.  `native=False` forces the
+    autograd form.  `wide`: the inputs exceed the 16-bit operand range (None: model.operand_range == "wide")."""
     if native is None:
         native = NativeTrainStep.applicable(model)
+    if wide is None:
+        wide = getattr(model, "operand_range", "auto") == "wide"
     if native:
-        return NativeTrainStep(model, batch, lr=lr, weight_decay=weight_decay, use_graph=use_graph, split=split)
-    return AutogradTrainStep(model, batch, lr=lr, weight_decay=weight_decay, use_graph=use_graph, split=split)
+        return NativeTrainStep(model, batch, lr=lr, weight_decay=weight_decay, use_graph=use_graph, split=split,
+                               wide=wide)
+    return AutogradTrainStep(model, batch, lr=lr, weight_decay=weight_decay, use_graph=use_graph, split=split,
+                             wide=wide)

@@ -158,6 +158,10 @@ class Main:
             model_save_path = self.env_config["load_model_path"]
         else:
             model_save_path = self.get_save_path()[0]
+            # raw engineering units (the reference's main.py normalises nothing; scripts/process_*.py do, offline):
+            # the resident training series is looked at once and the step runs on the fp32 row-gather kernels when
+            # it exceeds the 16-bit operand range of the matrix-core ones (include/gdn_hip.h "range guard")
+            self.train_config.setdefault("wide", self.model.train().input_exceeds_limit(self.train_series, margin=16.0))
             self.train_log = harness.train(self.model, model_save_path, config=self.train_config,
                                            train_dataloader=self.train_dataloader, val_dataloader=self.val_dataloader,
                                            use_graph=bool(self.train_config.get("hip_graph", True)))
@@ -166,7 +170,9 @@ class Main:
         # test.py's loop with the windows built in the kernel from the resident series (stride 1)
         w = self.train_config["slide_win"]
         n_test = self.test_series.shape[1] - w
-        pred = best_model.forward_series(self.test_series, 0, n_test) if best_model.out_layer_num == 1 else \
+        pred = best_model.forward_series(self.test_series, 0, n_test,
+                                         wide=best_model.input_exceeds_limit(self.test_series)) \
+            if best_model.out_layer_num == 1 else \
             torch.cat([best_model(x, None) for x, _y, _l, _e in IndexLoader(
                 self.test_dataset, torch.arange(n_test), self.train_config["batch"], False, None)])
         gt = self.test_series[:, w:].t().contiguous()

@@ -76,11 +76,11 @@ class _GraphAttentionFn(torch.autograd.Function):
     (reference models/graph_layer.py:53-117 and the autograd graph behind train.py:72)."""
 
     @staticmethod
-    def forward(ctx, x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, bias, graph, batch, terms):
-        xlin, s_i, s_j = ops.project_fwd(x, lin_w, terms)
-        z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, graph, bias, batch, want_alpha=True)
+    def forward(ctx, x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, bias, graph, batch, terms, wide=False):
+        xlin, s_i, s_j = ops.project_fwd(x, lin_w, terms, wide=wide)
+        z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, graph, bias, batch, want_alpha=True, wide=wide)
         ctx.save_for_backward(x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, xlin, s_i, s_j, alpha)
-        ctx.graph, ctx.batch = graph, batch
+        ctx.graph, ctx.batch, ctx.wide = graph, batch, wide
         ctx.mark_non_differentiable(alpha)
         return z, alpha
 
@@ -88,11 +88,11 @@ class _GraphAttentionFn(torch.autograd.Function):
     def backward(ctx, d_z, _d_alpha):
         x, lin_w, att_i, att_j, att_em_i, att_em_j, emb, xlin, s_i, s_j, alpha = ctx.saved_tensors
         d_xlin, d_si, d_sj, d_bias = ops.attn_aggregate_bwd(d_z.contiguous(), xlin, alpha, s_i, s_j,
-                                                            ctx.graph, ctx.batch)
+                                                            ctx.graph, ctx.batch, wide=ctx.wide)
         d_lin_w, d_a, d_c = ops.project_bwd(x, d_xlin, d_si, d_sj, lin_w.shape[0])
         d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb = ops.terms_bwd(
             lin_w, att_i, att_j, att_em_i, att_em_j, emb, d_lin_w, d_a, d_c)
-        return None, d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb, d_bias, None, None, None
+        return None, d_lin_w, d_att_i, d_att_j, d_att_em_i, d_att_em_j, d_emb, d_bias, None, None, None, None
 
 
 class _HeadTrainFn(torch.autograd.Function):
@@ -223,7 +223,8 @@ class OutLayer(nn.Module):
 
 
 class _EvalConstants:
-    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans", "mlp", "stream", "ready")
+    __slots__ = ("key", "graph", "terms", "bn1", "bn2", "fused_args", "plans", "mlp", "stream", "ready", "guards",
+                 "limits")
 
 
 class GDN(nn.Module):
@@ -252,6 +253,13 @@ class GDN(nn.Module):
         self.cache_embed_index = None
         self.dp = nn.Dropout(0.2)
         self.injected_graph = None      # optional [N,K] int64 table overriding the learned top-k
+        # Range of the inputs (include/gdn_hip.h "range guard"): the matrix-core kernels carry fp32 inputs as two
+        # f16 terms, which end at 65504.  "auto": the eval fast path detects out-of-range windows ON THE DEVICE and
+        # recomputes the launch in fp32 (no synchronisation); the staged / training paths compare max|x| with the
+        # limit on the host (one synchronisation per call).  "narrow" / "wide": the caller knows (harness.train,
+        # SeriesEvaluator and python -m gdn_amd.main look at the data they hold once): no check, matrix-core /
+        # fp32 row-gather kernels respectively.
+        self.operand_range = "auto"
         self._consts = None
         self.init_params()
 
@@ -303,6 +311,8 @@ class GDN(nn.Module):
         c.bn1 = c.bn2 = None
         c.fused_args = None
         c.plans = {}                 # bf16_storage -> plan tensor (or None: shape not on the matrix-core path)
+        c.guards = {}                # stream -> int32[2] range guard of the eval fast path
+        c.limits = {}                # bf16_storage -> the plan's x limit as a host float (read on first use)
         c.mlp = False                # eval-mode OutLayer MLP plan: False = not built yet, None = unsupported
         if not self.training:
             c.bn1 = ops.bn_fold(self.gnn_layers[0].bn)
@@ -324,10 +334,32 @@ class GDN(nn.Module):
         self._consts = c
         return c
 
-    def _launch_fused(self, x, c, out, keys=None):
-        """One ctypes call; every argument except x / out comes from the constants cache.  `keys` = (gt[B, n]
-        fp32, device pointer of the float64 key rows, row pitch): the launch also leaves the scoring keys
-        |out - gt| (planned matrix-core path only)."""
+    def _wait_ready(self, c):
+        """Launches from another stream order themselves behind the constants / plan, which were built on
+        `c.stream` (a capture is preceded by a warm-up + synchronize: nothing to wait for)."""
+        cur = torch.cuda.current_stream()
+        if c.ready is not None and cur != c.stream and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(c.ready)
+        return cur
+
+    def _guard(self, c, stream):
+        """The int32[2] range guard of this stream (zero: the gated launch leaves it zeroed)."""
+        g = c.guards.get(stream.cuda_stream)
+        if g is None:
+            with torch.cuda.stream(c.stream) if c.stream is not None else contextlib.nullcontext():
+                g = torch.zeros((2,), dtype=torch.int32, device=self.embedding.weight.device)
+                if c.ready is not None:
+                    c.ready = torch.cuda.Event()
+                    c.ready.record(c.stream)
+            c.guards[stream.cuda_stream] = g
+        return g
+
+    def _launch_fused(self, x, c, out, keys=None, guard: bool = False, wide: bool = False):
+        """One ctypes call (two with the range guard); every argument except x / out comes from the constants
+        cache.  `keys` = (gt[B, n] fp32, device pointer of the float64 key rows, row pitch): the launch also
+        leaves the scoring keys |out - gt| (planned matrix-core path only).  `wide`: the inputs are known to
+        exceed the 16-bit operand range — fp32 row-gather kernel.  `guard`: they are not known — the planned
+        launch flags out-of-range windows and a gated row-gather launch on the same stream redoes them."""
         if not x.is_cuda:
             raise _lib.GdnHipError(f"input is on {x.device}: gdn_amd needs a HIP device (no CPU fallback)")
         ptrs, n, w, d, k = c.fused_args
@@ -335,10 +367,9 @@ class GDN(nn.Module):
         if x.shape[1] != n or x.shape[2] != w:
             raise ValueError(f"expected data of shape [B, {n}, {w}], got {tuple(x.shape)}")
         bf16 = x.dtype == torch.bfloat16
-        plan = self._plan(c, bf16)
-        cur = torch.cuda.current_stream()
-        if c.ready is not None and cur != c.stream and not torch.cuda.is_current_stream_capturing():
-            cur.wait_event(c.ready)      # (a capture is preceded by a warm-up + synchronize: nothing to wait for)
+        plan = None if (wide and not bf16) else self._plan(c, bf16)
+        g = self._guard(c, torch.cuda.current_stream()) if (guard and plan is not None and not bf16) else None
+        cur = self._wait_ready(c)
         st = cur.cuda_stream
         if keys is not None:
             if plan is None:
@@ -348,11 +379,58 @@ class GDN(nn.Module):
                       key_ptr, key_pitch, b, n, w, d, k, int(bf16), out.data_ptr(), st)
         elif plan is not None:
             _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, int(bf16),
-                      out.data_ptr(), st)
+                      out.data_ptr(), None if g is None else g.data_ptr(), st)
+            if g is not None:       # no-op unless the launch above met a value outside the operand range
+                _lib.call("gdn_forward_fused_gated", g.data_ptr(), x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(), st)
+        elif wide and not bf16:
+            _lib.call("gdn_forward_fused_gated", None, x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(), st)
         else:
             _lib.call("gdn_forward_fused_bf16" if bf16 else "gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k,
                       out.data_ptr(), st)
         return out
+
+    def operand_limit(self, bf16: bool = False) -> float:
+        """Largest |x| the eval fast path's matrix-core kernel represents with the current parameters (inf: no
+        limit — bf16 storage, or a shape that runs on the fp32 row-gather kernels anyway).  Reads one float of
+        the plan: a host synchronisation, cached until the parameters change."""
+        c = self._constants()
+        if bf16 not in c.limits:
+            plan = self._plan(c, bf16) if c.fused_args is not None else None
+            if plan is None:
+                c.limits[bf16] = float("inf")
+            else:
+                _, n, w, d, k = c.fused_args
+                c.limits[bf16] = float(ops.fused_plan_limit(plan, n, w, d, k, bf16))
+        return c.limits[bf16]
+
+    def input_exceeds_limit(self, data: torch.Tensor, margin: float = 1.0) -> bool:
+        """True when `data` (windows or a raw series, already on the device) holds a value the matrix-core
+        kernels cannot represent (|x| >= the limit, or NaN): callers that keep their data resident ask ONCE and
+        pass `wide=` afterwards.  Three small reductions + ONE synchronisation.  The limit covers every kernel
+        family: the fused kernel's plan limit (eval, out_layer_num == 1), and for the staged / training kernels
+        |x| < 60000 and |xlin| <= |x| * max_c sum_w |lin[c, w]| < 60000.  `margin` > 1 tightens the limit by that
+        factor (training: the weights the limit was computed from move)."""
+        if data.dtype == torch.bfloat16:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("operand_range='auto' needs a host check: set model.operand_range to 'narrow' or "
+                               "'wide' before capturing (harness.GraphedTrainStep does)")
+        l1 = self.gnn_layers[0].gnn.lin.weight.detach().abs().sum(dim=1).amax().clamp_min(1e-30)
+        limit = torch.clamp(60000.0 / l1, max=60000.0)
+        if not self.training and self.out_layer_num == 1:
+            c = self._constants()
+            plan = self._plan(c, False)
+            if plan is not None:
+                _, n, w, d, k = c.fused_args
+                limit = torch.minimum(limit, ops.fused_plan_limit(plan, n, w, d, k, False))
+        return not bool(data.detach().abs().amax() * margin < limit)            # (NaN compares false: wide)
+
+    def _wide_for(self, x) -> bool:
+        if self.operand_range == "wide":
+            return x.dtype != torch.bfloat16
+        if self.operand_range == "narrow":
+            return False
+        return self.input_exceeds_limit(x)
 
     def _plan(self, c, bf16: bool):
         """The fused kernel's precomputed per-launch constants for these parameters (built on first use,
@@ -389,11 +467,13 @@ class GDN(nn.Module):
         if not self.training:
             if self.out_layer_num == 1:
                 out = torch.empty((batch, node_num), dtype=torch.float32, device=x.device)
-                self._launch_fused(x, c, out)
+                mode = self.operand_range
+                self._launch_fused(x, c, out, guard=mode == "auto", wide=mode == "wide")
                 layer._set_dense(lambda: self._dense_attention(x, c, batch))
                 return out
-            xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
-            z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True)
+            wide = self._wide_for(x)
+            xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms, wide=wide)
+            z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True, wide=wide)
             layer._set_dense((alpha, c.graph, batch))
             # out_layer_num > 1: the head kernel hands its [BN,d] activation to the OutLayer MLP
             # (plain library GEMMs through torch); its own Linear(d->1) result is unused here
@@ -410,7 +490,7 @@ class GDN(nn.Module):
 
         # ---- training: HIP forward/backward for the graph layer and (out_layer_num == 1) the head
         z, alpha = _GraphAttentionFn.apply(x, gnn.lin.weight, gnn.att_i, gnn.att_j, gnn.att_em_i,
-                                           gnn.att_em_j, emb, gnn.bias, c.graph, batch, c.terms)
+                                           gnn.att_em_j, emb, gnn.bias, c.graph, batch, c.terms, self._wide_for(x))
         layer._set_dense((alpha, c.graph, batch))
         if self.out_layer_num == 1 and self._hip_train_head_ok():
             lin = self.out_layer.mlp[0]
@@ -462,23 +542,25 @@ class GDN(nn.Module):
             self._ones = None if getattr(dp, "inplace", False) else ones
         return dp(ones).reshape(batch * node_num, d), 1.0
 
-    def forward_into(self, data, out, keys=None):
+    def forward_into(self, data, out, keys=None, wide: bool = False):
         """Eval fast path writing into a caller-owned [B, N] slice (no allocation, HIP-graph
-        capturable once `_constants()` is warm): used by harness.SeriesEvaluator.  `keys`: see _launch_fused."""
+        capturable once `_constants()` is warm): used by harness.SeriesEvaluator.  `keys`: see _launch_fused.
+        The caller vouches for the range of `data` (`input_exceeds_limit`, asked once per resident tensor):
+        `wide=True` runs the fp32 row-gather kernel, False the matrix-core one WITHOUT the range guard."""
         if self.training or self.out_layer_num != 1:
             raise RuntimeError("forward_into is the eval / out_layer_num == 1 fast path")
         c = self._constants()
         self.learned_graph = c.graph.topk
         if data.dtype not in (torch.float32, torch.bfloat16):
             data = data.float()
-        return self._launch_fused(data.contiguous(), c, out, keys)
+        return self._launch_fused(data.contiguous(), c, out, keys, wide=wide)
 
     def fused_keys_supported(self, bf16: bool = False) -> bool:
         """True when the eval forward of this model can leave the scoring keys itself (`keys=` of forward_into /
         forward_series): out_layer_num == 1 on the planned matrix-core path."""
         return (not self.training) and self.out_layer_num == 1 and self._plan(self._constants(), bf16) is not None
 
-    def forward_series(self, series, first: int, batch: int, out=None, keys=None):
+    def forward_series(self, series, first: int, batch: int, out=None, keys=None, wide: bool = False):
         """Eval forward of `batch` consecutive stride-1 windows taken directly from the raw series
         [node_num, T] (the layout `TimeDataset` slices, datasets/TimeDataset.py:42-49): window b is
         series[:, first+b : first+b+W] and predicts column first+b+W.  No [T, N, W] tensor exists."""
@@ -488,30 +570,37 @@ class GDN(nn.Module):
         gnn = self.gnn_layers[0].gnn
         lin = self.out_layer.mlp[0]
         self.learned_graph = c.graph.topk
-        plan = self._plan(c, False)
+        plan = None if wide else self._plan(c, False)
+        st = self._wait_ready(c).cuda_stream
+        series = ops._chk(series, name="series")
+        n, t_len = series.shape
+        d, w = gnn.lin.weight.shape
+        if out is None:
+            out = torch.empty((batch, n), dtype=torch.float32, device=series.device)
         if plan is not None:
-            series = ops._chk(series, name="series")
-            n, t_len = series.shape
-            d, w = gnn.lin.weight.shape
-            if out is None:
-                out = torch.empty((batch, n), dtype=torch.float32, device=series.device)
             if keys is not None:
                 gt, key_ptr, key_pitch = keys
                 _lib.call("gdn_forward_fused_series_plan_keys", series.data_ptr(), t_len, first, plan.data_ptr(),
                           ops._chk(gt, name="gt").data_ptr(), key_ptr, key_pitch, batch, n, w, d, c.graph.k,
-                          out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                          out.data_ptr(), st)
                 return out
             _lib.call("gdn_forward_fused_series_plan", series.data_ptr(), t_len, first, plan.data_ptr(), batch, n, w, d,
-                      c.graph.k, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                      c.graph.k, out.data_ptr(), None, st)
             return out
         if keys is not None:
             raise _lib.GdnHipError("scoring keys from the forward launch need the planned matrix-core path")
-        return ops.forward_fused_series(series, first, batch, gnn.lin.weight.shape[1], gnn.lin.weight, c.terms,
+        if wide:     # the fp32 row-gather kernel on the raw series (inputs beyond the 16-bit operand range)
+            ptrs = c.fused_args[0]
+            _lib.call("gdn_forward_fused_series_gated", None, series.data_ptr(), t_len, first, *ptrs, batch, n, w, d,
+                      c.graph.k, out.data_ptr(), st)
+            return out
+        return ops.forward_fused_series(series, first, batch, w, gnn.lin.weight, c.terms,
                                         c.graph, gnn.bias, self.embedding.weight, c.bn1, c.bn2, lin.weight,
                                         lin.bias, out=out)
 
     def _dense_attention(self, x, c, batch):
         gnn = self.gnn_layers[0].gnn
-        xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms)
-        _, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True)
+        wide = self._wide_for(x)
+        xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms, wide=wide)
+        _, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True, wide=wide)
         return alpha, c.graph, batch

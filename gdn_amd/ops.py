@@ -109,10 +109,13 @@ def _storage(t: torch.Tensor, name: str) -> str:
     return ""
 
 
-def project_fwd(x, lin_w, terms):
+def project_fwd(x, lin_w, terms, wide: bool = False):
     """x[B,n,w] -> xlin[B*n,d], s_i[B*n], s_j[B*n]  (models/graph_layer.py:56 + logit scalars).
-    bfloat16 x gives bfloat16 xlin (bf16 storage)."""
+    bfloat16 x gives bfloat16 xlin (bf16 storage).  `wide`: the fp32 row-gather kernels at every shape (inputs
+    beyond the 16-bit operand range of the matrix-core kernels, include/gdn_hip.h "range guard")."""
     sfx = _storage(x, "x")
+    if wide and not sfx:
+        sfx = "_wide"
     x = _chk(x, x.dtype, name="x")
     lin_w = _chk(lin_w.detach(), name="lin.weight")
     b, n, w = x.shape
@@ -125,9 +128,11 @@ def project_fwd(x, lin_w, terms):
     return xlin, s_i, s_j
 
 
-def attn_aggregate_fwd(xlin, s_i, s_j, graph: SensorGraph, bias, batch: int, want_alpha: bool):
+def attn_aggregate_fwd(xlin, s_i, s_j, graph: SensorGraph, bias, batch: int, want_alpha: bool, wide: bool = False):
     """models/graph_layer.py:65-74,82-117 -> z[B*n,d] (+ dense alpha[B*n,pitch])."""
     sfx = _storage(xlin, "xlin")
+    if wide and not sfx:
+        sfx = "_wide"
     xlin = _chk(xlin, xlin.dtype, name="xlin")
     bn, d = xlin.shape
     n = bn // batch
@@ -412,6 +417,13 @@ def fused_plan(lin_w, terms, graph: SensorGraph, gnn_bias, emb, bn1_affine, bn2_
     return plan
 
 
+def fused_plan_limit(plan: torch.Tensor, n: int, w: int, d: int, k: int, bf16_storage: bool = False) -> torch.Tensor:
+    """The plan's x limit (include/gdn_hip.h "range guard") as a 0-d float32 DEVICE tensor (a view of the plan:
+    reading it on the host is a synchronisation, done once per resident series)."""
+    off = _lib.load().gdn_fused_plan_limit_offset(n, w, d, k, int(bf16_storage))
+    return plan[off // 4].view(torch.float32)
+
+
 def forward_fused_series(series, first: int, batch: int, w: int, lin_w, terms, graph: SensorGraph, gnn_bias, emb,
                          bn1_affine, bn2_affine, out_w, out_b, out: torch.Tensor | None = None):
     """Fused eval forward of `batch` stride-1 windows read straight from series[n, T]
@@ -429,7 +441,7 @@ def forward_fused_series(series, first: int, batch: int, w: int, lin_w, terms, g
     return out
 
 
-def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: int):
+def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: int, wide: bool = False):
     """Gradient of attn_aggregate_fwd w.r.t. xlin, s_i, s_j and bias."""
     d_z = _chk(d_z, name="d_z")
     bn, d = d_z.shape
@@ -439,13 +451,14 @@ def attn_aggregate_bwd(d_z, xlin, alpha, s_i, s_j, graph: SensorGraph, batch: in
     d_sj = torch.empty_like(d_si)
     d_bias = torch.empty((d,), dtype=torch.float32, device=d_z.device)
     # the matrix-core backward (n <= 127, d = 64) does not read the reverse lists: they are not even built then
-    rent, rlen = graph.reverse() if _lib.load().gdn_attn_aggregate_bwd_uses_reverse(n, d, graph.k) else (None, None)
+    rent, rlen = graph.reverse() if wide or _lib.load().gdn_attn_aggregate_bwd_uses_reverse(n, d, graph.k) else (None, None)
     # [ticket, zero on entry | d_bias partial rows | d_pi tables when they exceed LDS]: a fresh one per call, so
     # calls on different streams never share a ticket (NativeTrainStep owns one for its stream instead)
     nbytes = _lib.load().gdn_attn_aggregate_bwd_workspace_bytes(batch, n, d, graph.k)
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=d_z.device)
     ws[:4].zero_()
-    _lib.call("gdn_attn_aggregate_bwd", _ptr(d_z), _ptr(_chk(xlin)), _ptr(_chk(alpha)), _ptr(_chk(s_i)),
+    _lib.call("gdn_attn_aggregate_bwd_wide" if wide else "gdn_attn_aggregate_bwd", _ptr(d_z), _ptr(_chk(xlin)),
+              _ptr(_chk(alpha)), _ptr(_chk(s_i)),
               _ptr(_chk(s_j)), _ptr(graph.nbr), _ptr(rent), _ptr(rlen), batch, n, d, graph.k,
               _ptr(d_xlin), _ptr(d_si), _ptr(d_sj), _ptr(d_bias), _ptr(ws), _stream())
     return d_xlin, d_si, d_sj, d_bias

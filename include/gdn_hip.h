@@ -332,9 +332,54 @@ int gdn_fused_plan_build(const float* lin_w, const float* node_terms, const uint
                          const float* out_b, int n, int w, int d, int k, int bf16_storage,
                          void* plan, void* stream);
 int gdn_forward_fused_plan(const void* x, const void* plan, int batch, int n, int w, int d, int k,
-                           int bf16_storage, float* out, void* stream);
+                           int bf16_storage, float* out, int* range_guard, void* stream);
 int gdn_forward_fused_series_plan(const float* series, int series_len, int first, const void* plan,
-                                  int batch, int n, int w, int d, int k, float* out, void* stream);
+                                  int batch, int n, int w, int d, int k, float* out, int* range_guard,
+                                  void* stream);
+
+/* ---- range guard ---------------------------------------------------------------------
+ * The reference computes in fp32 on whatever the caller feeds it (models/graph_layer.py:56).  The fp32-storage
+ * matrix-core kernels carry x, and the BatchNorm-folded projected tile times 8, as two f16 terms each: values
+ * of 65504 and beyond do not exist there.  Every plan therefore holds its X LIMIT, the largest |x| for which
+ * both are representable whatever the window: min(60000, (60000 - max_c |C-in[c]|) / max_c sum_w |lin'[c,w]|)
+ * (a float at byte gdn_fused_plan_limit_offset(...) of the plan; +inf for bf16 storage, whose terms have
+ * fp32's exponent range).  Normalised data (the reference's scripts/process_*.py: MinMax to [0, 1]) sits four
+ * orders of magnitude below it; raw engineering units may not.  Two ways to stay exact for ANY input:
+ *   (a) known data (a resident series): compare max|x| with the limit once and call the `_gated` entry points
+ *       below with guard = null — the fp32 row-gather kernels, fp32's own range — when it is exceeded;
+ *   (b) unknown data (GDN.forward on a caller's tensor): pass `range_guard` (2 ints, ZERO before the first
+ *       call) to the planned launch — it stores 1 in range_guard[0] when a window holds |x| >= limit or a
+ *       NaN — and follow it on the same stream with the gated launch on the same guard: a no-op (every
+ *       workgroup returns at once) unless the flag is up, in which case it recomputes the launch's windows
+ *       in fp32 and leaves the guard zeroed.  No host synchronisation, hipGraph-capturable; one guard per
+ *       stream.  range_guard = null: no detection (the `_keys` launches never detect: use (a)).
+ * The staged kernels have `_wide` twins that always take the row-gather path (training on raw-unit data:
+ * harness.train / python -m gdn_amd.main compare the data they hold with GDN_WIDE_LIMIT once).          */
+long long gdn_fused_plan_limit_offset(int n, int w, int d, int k, int bf16_storage);
+int gdn_forward_fused_gated(int* guard, const float* x, const float* lin_w, const float* node_terms,
+                            const uint16_t* nbr, const int32_t* deg, const float* gnn_bias,
+                            const float* emb, const float* bn1_affine, const float* bn2_affine,
+                            const float* out_w, const float* out_b,
+                            int batch, int n, int w, int d, int k, float* out, void* stream);
+int gdn_forward_fused_series_gated(int* guard, const float* series, int series_len, int first,
+                                   const float* lin_w, const float* node_terms, const uint16_t* nbr,
+                                   const int32_t* deg, const float* gnn_bias, const float* emb,
+                                   const float* bn1_affine, const float* bn2_affine, const float* out_w,
+                                   const float* out_b, int batch, int n, int w, int d, int k, float* out,
+                                   void* stream);
+int gdn_project_fwd_wide(const float* x, const float* lin_w, const float* node_terms,
+                         int batch, int n, int w, int d,
+                         float* xlin, float* s_i, float* s_j, void* stream);
+int gdn_attn_aggregate_fwd_wide(const float* xlin, const float* s_i, const float* s_j,
+                                const uint16_t* nbr, const int32_t* deg, const float* bias,
+                                int batch, int n, int d, int k,
+                                float* z, float* alpha, void* stream);
+int gdn_attn_aggregate_bwd_wide(const float* d_z, const float* xlin, const float* alpha,
+                                const float* s_i, const float* s_j,
+                                const uint16_t* nbr, const uint32_t* rent, const int32_t* rlen,
+                                int batch, int n, int d, int k,
+                                float* d_xlin, float* d_si, float* d_sj, float* d_bias,
+                                float* workspace, void* stream);
 
 /* The two planned launches with the scoring hand-off folded into their epilogue: besides out[B, n] they leave
  * keys[sensor * key_pitch + b] = |out[b][sensor] - gt[b][sensor]| in float64 — the radix keys

@@ -334,3 +334,103 @@ def test_integration_md_ctypes_stub_runs(gpu_device):
     # (the packaged forward goes through a plan, which reorders each lane's list slots: same numbers to rounding)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-7, rtol=0)
     assert torch.equal(model.learned_graph, model._constants().graph.topk)
+
+
+# ---------------------------------------------------------------- inputs beyond the 16-bit operand range
+def _oracle64(p, x, k, graph, layers=1):
+    f64 = torch.float64
+    p64 = {key: (v.to(f64) if v.is_floating_point() else v) for key, v in p.items()}
+    return gdn_oracle.forward(p64, x.to(f64), k, layers, graph=graph)["out"]
+
+
+def _assert_fp32_grade(got, p, x, k, graph, what=""):
+    """`got` against float64, as close as fp32 arithmetic gets: at large input scales the logits are O(1e3) and
+    the softmax is nearly one-hot, so an fp32 forward — the reference's own — is off by up to 1e-4 .. 1e-2 of the
+    output scale on the targets whose two largest logits nearly tie.  The bound is therefore the op-faithful fp32
+    oracle's own worst deviation from float64 (x4) plus the usual 2e-5 of the output scale."""
+    ref = _oracle64(p, x, k, graph)
+    ref32 = gdn_oracle.forward(p, x, k, 1, graph=graph)["out"].double()
+    scale = max(1.0, float(ref.abs().max()))
+    bound = 4.0 * float((ref32 - ref).abs().max()) + 2e-5 * scale
+    err = float((got.cpu().double() - ref).abs().max())
+    assert err <= bound, (what, err, bound, scale)
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.0e3, 1.0e5, 3.0e7])
+def test_raw_unit_inputs_equal_the_float64_oracle_without_any_switch(scale, gpu_device):
+    """The reference takes any fp32 input (models/graph_layer.py:56); the matrix-core kernels carry x as two f16
+    terms, which end at 65504.  `model(x)` must still equal float64 on inputs in raw engineering units — no
+    environment variable, no flag, no host synchronisation: the planned launch raises its range guard, the gated
+    fp32 row-gather launch behind it recomputes the batch (include/gdn_hip.h "range guard").  Batches inside the
+    range (scale 1, 3e3) must come from the matrix-core kernel alone, and a guard raised by one call must not
+    leak into the next."""
+    n, w, k, d, b = 127, 15, 30, 64, 37
+    model = random_params(n, w, k, d, seed=31)
+    p = {key: v.detach().clone() for key, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand((b, n, w), generator=g) * scale
+    x[3, 5, 2] = -x[3, 5, 2]
+    with torch.no_grad():
+        out = model(x.to(gpu_device), None)
+        graph = model.learned_graph.cpu()
+        _assert_fp32_grade(out, p, x, k, graph, what=f"scale {scale}")
+        c = model._constants()
+        guard = next(iter(c.guards.values()))
+        assert guard.tolist() == [0, 0]                       # whatever was raised has been consumed
+        limit = model.operand_limit()
+        assert 1e3 < limit <= 60000.0
+        assert model.input_exceeds_limit(x.to(gpu_device)) == (scale * 1.0 >= limit)
+        # a normal batch right after: the guard is down again, same result as a fresh model
+        x2 = torch.rand((b, n, w), generator=g)
+        out2 = model(x2.to(gpu_device), None)
+        np.testing.assert_allclose(out2.cpu().double().numpy(), _oracle64(p, x2, k, graph).numpy(), atol=2e-5, rtol=0)
+
+
+def test_evaluator_and_training_on_raw_unit_series(gpu_device):
+    """The resident-series callers look at their data ONCE: harness.SeriesEvaluator (windows or raw series) and
+    harness.train pick the fp32 row-gather kernels for a series in raw units (x 1e5) and the matrix-core ones for
+    the same series normalised; predictions equal float64 either way, and a training step on raw units produces
+    finite, oracle-accurate gradients through the captured native step."""
+    from gdn_amd import harness
+    n, w, k, d, t = 27, 10, 8, 64, 300
+    model = random_params(n, w, k, d, seed=33)
+    p = {key: v.detach().clone() for key, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    g = torch.Generator().manual_seed(34)
+    series = torch.rand((n, t + w), generator=g)
+    idx = torch.arange(t).view(-1, 1) + torch.arange(w).view(1, -1)
+    for scale, expect_wide in ((1.0, False), (1.0e5, True)):
+        raw = (series * scale).to(gpu_device)
+        xs = (series * scale)[:, idx].permute(1, 0, 2).contiguous()
+        y = raw[:, w:].t().contiguous()
+        ev = harness.SeriesEvaluator(model, None, y, batch=64, use_graph=True, series=raw)
+        assert ev.wide == expect_wide
+        ev.step()
+        with torch.no_grad():
+            model(xs[:1].to(gpu_device), None)
+        _assert_fp32_grade(ev.pred, p, xs, k, model.learned_graph.cpu(), what=f"series evaluator, scale {scale}")
+        ev2 = harness.SeriesEvaluator(model, xs.to(gpu_device), y, batch=64, use_graph=False)
+        assert ev2.wide == expect_wide
+        ev2.step()
+        _assert_fp32_grade(ev2.pred, p, xs, k, model.learned_graph.cpu(), what=f"window evaluator, scale {scale}")
+    # training on raw units: harness.train decides from the first batch and pins the model to the wide kernels
+    from _grad_check import assert_grads_close, oracle_step
+    xs = (series * 1.0e5)[:, idx].permute(1, 0, 2).contiguous()[:64]
+    ys = (series * 1.0e5)[:, w:].t().contiguous()[:64]
+    model.train()
+    model.dp.p = 0.0
+    assert model.input_exceeds_limit(xs.to(gpu_device), margin=16.0)
+    step = harness.GraphedTrainStep(model, 64, wide=True)
+    assert isinstance(step, harness.NativeTrainStep) and step.wide
+    step.x.copy_(xs.to(gpu_device)); step.y.copy_(ys.to(gpu_device))
+    start = {key: v.detach().clone() for key, v in model.state_dict().items()}
+    loss = float(step.step())
+    got = {name: step.flat_g[off:off + cnt].view(prm.shape)
+           for (name, prm), (off, cnt) in zip(model.named_parameters(), step.slices)}
+    ref_loss, want, _kink = oracle_step(start, xs, ys, step.ws["topk"].cpu(), 1, None)
+    assert abs(loss - ref_loss) <= 1e-5 * ref_loss
+    assert all(bool(torch.isfinite(v).all()) for v in got.values())
+    # (logits are O(1e5) here: the softmax is one-hot and its gradient is what survives cancellation, so fp32 —
+    # any fp32 — keeps 3 digits of the attention gradients, not 5: bounds widened accordingly)
+    assert_grads_close(got, want, tol_max=1e-3, tol_elem=0.5, what="raw-unit training step")

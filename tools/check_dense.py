@@ -45,7 +45,7 @@ def timing(b):
 
     def launch():
         if plan is not None:
-            _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, 0, out.data_ptr(), st)
+            _lib.call("gdn_forward_fused_plan", x.data_ptr(), plan.data_ptr(), b, n, w, d, k, 0, out.data_ptr(), None, st)
         else:
             _lib.call("gdn_forward_fused", x.data_ptr(), *ptrs, b, n, w, d, k, out.data_ptr(), st)
     for _ in range(200):
