@@ -34,6 +34,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SENSORS, WINDOW, TOPK, DIM = 127, 15, 30, 64
+# --workload: the headline is BASELINE configs[2]; configs[4] (the WADI-shape stress case) is a second line
+WORKLOADS = {
+    "swat": dict(n=127, w=15, k=30, label="BASELINE configs[2]: SWaT-shape eval forward + anomaly score"),
+    "config4": dict(n=512, w=30, k=64, label="BASELINE configs[4]: WADI-shape stress (512 sensors, top-k 64, W=30) "
+                                              "eval forward + anomaly score"),
+}
 
 
 def build_model(device):
@@ -83,14 +89,18 @@ def event_time_launches(launch, count, settle_ms=60.0):
 
 
 def pmc_traffic(kernel_key, batch):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) for this launch size, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            rec = json.load(f)["per_launch"][kernel_key][str(batch)]
-        return int(rec["fetch_bytes"] + rec["write_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch from the committed rocprofv3 PMC summaries (profiles/r03_pmc_traffic.json, else round
+    2's: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) for this launch size, or None."""
+    if N_SENSORS != 127:
+        kernel_key = f"{kernel_key}_n{N_SENSORS}_d{DIM}"
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)["per_launch"][kernel_key][str(batch)]
+            return int(rec["fetch_bytes"] + rec["write_bytes"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def k8_roofline(model, x, batch, launches, storage="fp32"):
@@ -103,6 +113,8 @@ def k8_roofline(model, x, batch, launches, storage="fp32"):
     emb = model.embedding.weight
     sfx = "_bf16" if storage == "bf16" else ""
     esz = 2 if storage == "bf16" else 4
+    if storage == "bf16" and not _lib.load().gdn_fused_plan_bytes(N_SENSORS, WINDOW, 64, TOPK, 1):
+        return None      # the staged bf16-storage kernels exist on the matrix-core path only (n <= 127)
     xs = x[:batch].bfloat16() if storage == "bf16" else x[:batch]
     xlin, s_i, s_j = ops.project_fwd(xs, gnn.lin.weight, c.terms)
     z = torch.empty_like(xlin)
@@ -130,7 +142,8 @@ def k8_roofline(model, x, batch, launches, storage="fp32"):
     # read xlin once + write z once + the neighbour lists once (alpha fused, not stored)
     alg_bytes = 2 * batch * N_SENSORS * DIM * esz + N_SENSORS * c.graph.pitch * 2
     achieved = alg_bytes / (mean_us * 1e-6) / 1e9
-    return {"kernel": f"gdn_attn_aggregate_fwd{sfx} (K8 gather-aggregate on the matrix cores, staged eval leg, "
+    how = "on the matrix cores" if N_SENSORS <= 127 and DIM == 64 else "fp32 row gather (n > 127: VALU family)"
+    return {"kernel": f"gdn_attn_aggregate_fwd{sfx} (K8 gather-aggregate {how}, staged eval leg, "
                       f"{storage} storage of xlin and z)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k8" + sfx, batch),
@@ -157,9 +170,15 @@ def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
     xs = x.bfloat16() if bf16 else x
     xstride, pstride = N_SENSORS * WINDOW * esz, N_SENSORS * 4
     nslots = max(1, x.shape[0] // batch)
+    if plan is None:                         # n > 127: the row-gather kernel (no plan on that path)
+        name = ("gdn_forward_fused_bf16" if bf16 else "gdn_forward_fused") + " (fp32 row gather, " + storage + " storage)"
 
     def launch(i):          # raw C-ABI call: host cost per launch stays below the kernel's duration
         s = (i % nslots) * batch
+        if plan is None:
+            _lib.call("gdn_forward_fused_bf16" if bf16 else "gdn_forward_fused", xs.data_ptr() + s * xstride, *fixed,
+                      batch, N_SENSORS, WINDOW, DIM, TOPK, pred.data_ptr() + s * pstride, st)
+            return
         _lib.call("gdn_forward_fused_plan", xs.data_ptr() + s * xstride, plan.data_ptr(), batch, N_SENSORS, WINDOW, DIM,
                   TOPK, int(bf16), pred.data_ptr() + s * pstride, None, st)
     for i in range(3):
@@ -172,9 +191,11 @@ def fused_roofline(model, x, pred, batch, launches, storage="fp32"):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused" + ("_bf16" if storage == "bf16" else ""), batch),
             "launch_us": round(mean_us, 2), "launch_us_best": round(med_us, 2), "batch": batch,
             "algorithmic_bytes_per_launch": alg_bytes, "windows_per_s": round(batch / (mean_us * 1e-6), 1),
-            "note": "by design only x-in + out touch HBM; the aggregation runs as a dense [n x n] x [n x d] product on "
-                    "v_mfma_f32_32x32x16 (two 16-bit terms per factor), bound by LDS operand traffic + VALU "
-                    "(profiles/r02_sq_counters*.json)"}
+            "note": ("by design only x-in + out touch HBM; the aggregation runs as a dense [n x n] x [n x d] product on "
+                     "v_mfma_f32_32x32x16 (two 16-bit terms per factor), bound by LDS operand traffic + VALU "
+                     "(profiles/r02_sq_counters*.json)") if plan is not None else
+                    "by design only x-in + out touch HBM; one workgroup per window, xlin tile in LDS, fp32 row gather on "
+                    "the VALU (profiles/r03_sq_counters_config4*.json)"}
 
 
 def streaming_copy_rate(device, mib=1024, reps=20):
@@ -196,27 +217,48 @@ def streaming_copy_rate(device, mib=1024, reps=20):
             "note": "torch tensor copy, read + write; K8's roofline.achieved at the same traffic volume is the comparable figure"}
 
 
-def train_step_line(device, n, w, batch, steps=50):
+def train_step_line(device, n, w, batch, steps=50, dist=None, split=False):
     """Extra (not the headline): one optimisation step of the reference's train() (train.py:52-66) at the
     same shape — harness.NativeTrainStep: HIP forward/backward, in-kernel dropout draw, gdn_adam_step over flat
-    buffers — replayed from one HIP graph."""
-    from gdn_amd.harness import GraphedTrainStep
+    buffers — replayed from one HIP graph.  With several ranks (BASELINE configs[3]: global batch = ranks x
+    `batch`, DDP) the step is two graphs around ONE collective, the RCCL all-reduce of the flat gradient bucket
+    (sum; 1/ranks folded into the optimizer kernel); every rank runs it, the time is the max over ranks."""
+    from gdn_amd.harness import GraphedTrainStep, world
     model = build_model(device)[0].train()
-    step = GraphedTrainStep(model, batch)
-    step.x.copy_(torch.rand_like(step.x))
-    step.y.copy_(torch.rand_like(step.y))
+    step = GraphedTrainStep(model, batch, split=True if split else None)
+    g = torch.Generator(device=device).manual_seed(11 + world()[0])
+    step.x.copy_(torch.rand(step.x.shape, device=device, generator=g))
+    step.y.copy_(torch.rand(step.y.shape, device=device, generator=g))
     for _ in range(3):
         step.step()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step.step()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"batch": batch, "ms_per_step": round(ms, 4), "windows_per_s": round(batch / ms * 1e3, 1),
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ranks = world()[1]
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = dt / steps * 1e3
+    native = type(step).__name__ == "NativeTrainStep"
+    return {"batch": batch, "global_batch": batch * ranks, "ranks": ranks, "ms_per_step": round(ms, 4),
+            "windows_per_s": round(batch * ranks / ms * 1e3, 1),
             "step_impl": type(step).__name__, "optimizer": "gdn_adam_step (torch.optim.Adam update, flat buffers)"
-            if type(step).__name__ == "NativeTrainStep" else "torch.optim.Adam(fused)",
-            "hip_graph": True, "sensors": n, "window": w}
+            if native else "torch.optim.Adam(fused)",
+            "hip_graph": True, "sensors": n, "window": w,
+            "collective": ("one all_reduce (sum) of the flat fp32 gradient buffer, %d values, between two graph replays"
+                           % step.count) if (native and getattr(step, "_split", False)) else None,
+            "workload": "BASELINE configs[3] (global batch = ranks x 512, per-rank BatchNorm statistics)"
+            if ranks > 1 else "single-GPU training step at the bench shape"}
 
 
 def cpu_baseline(params, budget_s=12.0):
@@ -225,7 +267,9 @@ def cpu_baseline(params, budget_s=12.0):
     import numpy as np
     from oracle import gdn_oracle, score_oracle
     g = torch.Generator().manual_seed(0)
-    b = 512
+    # (the reference materialises [E, 1, 2d] edge tensors, E = b * n * (k+1): 512 windows of the 512-sensor shape
+    # would be 17 M edges x 1 KB — a bounded sample of 32 windows there)
+    b = 512 if N_SENSORS <= 127 else 32
     x = torch.rand((b, N_SENSORS, WINDOW), generator=g)
     with torch.no_grad():
         gdn_oracle.forward(params, x, TOPK)                       # warm-up
@@ -286,7 +330,13 @@ def run():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="1 rank, but run the N>1 step (RCCL process group, all-to-all scoring exchange)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="swat",
+                    help="swat = BASELINE configs[2] (the headline); config4 = the 512-sensor stress shape")
+    ap.add_argument("--dim", type=int, default=64, help="embedding / hidden width d (config4 is quoted at 64 and 128)")
     args = ap.parse_args()
+    global N_SENSORS, WINDOW, TOPK, DIM
+    wl = WORKLOADS[args.workload]
+    N_SENSORS, WINDOW, TOPK, DIM = wl["n"], wl["w"], wl["k"], args.dim
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -334,7 +384,7 @@ def run():
     launches_for = lambda b: max(12, min(64, 65536 // b))
     sizes = sorted({batch, min(4096, t), launch_batch, t})      # 4096: the launch size rounds 1-2 quoted
     sweep = [k8_roofline(model, x, b, launches=launches_for(b)) for b in sizes]
-    if world == 1 and args.sweep_max > t:       # the fraction at the largest per-GPU launch
+    if world == 1 and args.sweep_max > t and args.workload == "swat":   # the largest per-GPU launch
         xbig = torch.rand((args.sweep_max, N_SENSORS, WINDOW), device=device)     # 2 GB; xlin + z: 17 GB
         sweep.append(k8_roofline(model, xbig, args.sweep_max, launches=12))
         del xbig
@@ -343,7 +393,8 @@ def run():
     fused_sweep = [fused_leg if b == launch_batch else fused_roofline(model, x, ev.pred, b, launches=launches_for(b))
                    for b in sizes]
     # BASELINE configs[2] says bf16: the same kernels with x / xlin / z stored in bf16 (fp32 arithmetic)
-    sweep_bf16 = [k8_roofline(model, x, b, launches=launches_for(b), storage="bf16") for b in sizes]
+    sweep_bf16 = [r for r in (k8_roofline(model, x, b, launches=launches_for(b), storage="bf16") for b in sizes)
+                  if r is not None]
     fused_leg_bf16 = fused_roofline(model, x, ev.pred, launch_batch, launches=launches_for(launch_batch), storage="bf16")
 
     def timed(fn, steps):
@@ -389,14 +440,16 @@ def run():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * t / (elapsed / args.steps)
         result = {
-            "metric": "sliding-windows/sec forward+anomaly-score, SWaT-shape (127 sensors, W=15)",
+            "metric": "sliding-windows/sec forward+anomaly-score, SWaT-shape (127 sensors, W=15)" if args.workload == "swat"
+            else "sliding-windows/sec forward+anomaly-score, WADI-shape stress (512 sensors, W=30)",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: SWaT-shape eval forward + anomaly score",
+            "config": {"workload": wl["label"],
                        "sensors": N_SENSORS, "window": WINDOW, "topk": TOPK, "dim": DIM, "out_layer_num": 1,
                        "batch": batch, "batches_per_launch": max(1, args.coalesce),
                        "windows_per_launch": launch_batch, "windows_per_rank_per_step": t, "storage": "fp32",
+                       "multi_gpu_measured": world > 1,
                        "hip_graph": not args.no_graph, "forward_streams": args.streams, "step_impl": step_impl,
                        "parallelism": f"windows sharded over {world} rank(s), no forward collective; scoring keys "
                                       f"all-to-all by sensor in chunks of {args.exchange_chunk} ticks (async, overlapping "
@@ -412,17 +465,18 @@ def run():
         result["roofline_fused"] = fused_leg
         result["roofline_fused_sweep"] = [{"batch": r["batch"], "launch_us": r["launch_us"], "windows_per_s": r["windows_per_s"]}
                                           for r in fused_sweep]
-        result["roofline_bf16"] = next(r for r in sweep_bf16 if r["batch"] == launch_batch)
-        result["roofline_bf16_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
-                                          "launch_us": r["launch_us"]} for r in sweep_bf16]
+        if sweep_bf16:
+            result["roofline_bf16"] = next(r for r in sweep_bf16 if r["batch"] == launch_batch)
+            result["roofline_bf16_sweep"] = [{"batch": r["batch"], "achieved": r["achieved"], "frac": r["frac"],
+                                              "launch_us": r["launch_us"]} for r in sweep_bf16]
         result["roofline_fused_bf16"] = fused_leg_bf16
-        if args.coalesce > 1 and world == 1:      # transparency: the same step with one launch per logical minibatch
+        if args.coalesce > 1 and world == 1 and not args.rehearse_dist:      # transparency: the same step with one launch per logical minibatch
             ev1 = harness.SeriesEvaluator(model, x, y, batch=batch, use_graph=not args.no_graph, streams=args.streams)
             for _ in range(args.warmup):
                 ev1.step()
             preroll(ev1.step)
             result["value_per_batch_launches"] = round(t * args.steps / timed(ev1.step, args.steps), 1)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.rehearse_dist:
         # the same step on bf16-stored windows (BASELINE configs[2] wording; `value` stays the fp32 line)
         evb = harness.SeriesEvaluator(model, x.bfloat16(), y, batch=batch, use_graph=not args.no_graph,
                                       streams=args.streams, coalesce=args.coalesce)
@@ -431,17 +485,34 @@ def run():
         preroll(evb.step)
         result["value_bf16_storage"] = round(t * args.steps / timed(evb.step, args.steps), 1)
         del evb
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.rehearse_dist:
         # the same step with the windows built in-kernel from the raw [N, T+W] series
         raw = torch.rand((N_SENSORS, t + WINDOW), generator=torch.Generator().manual_seed(7)).to(device)
         ev2 = harness.SeriesEvaluator(model, None, raw[:, WINDOW:].t().contiguous(), batch=batch,
                                       use_graph=not args.no_graph, streams=args.streams, coalesce=args.coalesce,
                                       series=raw)
-        for _ in range(args.warmup):
-            ev2.step()
-        preroll(ev2.step)
-        result["value_windows_from_raw_series"] = round(t * args.steps / timed(ev2.step, args.steps), 1)
-        result["train_step"] = train_step_line(device, n=x.shape[1], w=x.shape[2], batch=args.batch)
+        from gdn_amd._lib import GdnHipError
+        try:
+            for _ in range(args.warmup):
+                ev2.step()
+            preroll(ev2.step)
+            result["value_windows_from_raw_series"] = round(t * args.steps / timed(ev2.step, args.steps), 1)
+        except GdnHipError as exc:      # n > 127 with n * w beyond the row-gather kernel's in-kernel window addressing
+            result["value_windows_from_raw_series"] = None
+            result["value_windows_from_raw_series_note"] = f"not available at this shape: {exc}"
+        del ev2, raw
+    # training step (BASELINE configs[3] with several ranks): every rank takes part in the gradient all-reduce
+    if args.workload == "swat" or world == 1:
+        from gdn_amd import _lib
+        if _lib.load().gdn_train_supported(N_SENSORS, WINDOW, DIM, TOPK):
+            line = train_step_line(device, n=x.shape[1], w=x.shape[2], batch=args.batch, dist=dist,
+                                   split=world > 1 or args.rehearse_dist)
+        else:       # 512 sensors at d = 128: the backward's [n+1, d] fp32 tile (263 KB) exceeds the 160 KB of LDS
+            line = {"ms_per_step": None, "note": "gdn_train_supported() == 0 at this shape: the backward keeps the whole "
+                                                  "[n+1, d] fp32 tile in LDS (no column slicing yet)"}
+        if rank == 0:
+            result["train_step"] = line
+    if rank == 0 and world == 1:
         result["streaming_copy"] = streaming_copy_rate(device)
         if not args.skip_cpu:
             result["cpu_baseline"] = cpu_baseline(params)

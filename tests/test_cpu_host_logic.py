@@ -122,3 +122,38 @@ def test_edge_list_views_follow_the_reference_format():
     layer._set_dense((alpha, graph, b))
     np.testing.assert_array_equal(layer.edge_index_1.numpy(), ei)
     np.testing.assert_allclose(layer.att_weight_1.numpy().reshape(-1), att)
+
+
+def test_flat_adam_does_not_average_twice(monkeypatch):
+    """harness.train averages the ragged batch's gradients over the ranks itself (sync_gradients) before it calls
+    optimizer.step(): the flat optimizer must then apply them as they are (grad_scale 1), while the captured
+    step — whose flat buffer holds the all-reduced SUM — folds 1/ranks into the optimizer kernel."""
+    import torch
+    from gdn_amd import harness
+    monkeypatch.setattr(harness, "world", lambda: (0, 4))
+    seen = []
+
+    class Owner:
+        params = [torch.nn.Parameter(torch.ones(3))]
+        slices = [(0, 3)]
+        flat_g = torch.zeros(4)
+        model = type("M", (), {"invalidate_constants": staticmethod(lambda: None)})()
+
+        def _adam(self, grad_scale=None):
+            seen.append(grad_scale)
+    owner = Owner()
+    owner.params[0].grad = torch.full((3,), 2.0)
+    harness._FlatAdam(owner).step()
+    assert seen == [1.0] and owner.flat_g[:3].tolist() == [2.0, 2.0, 2.0]
+    # the captured step's own call: grad_scale None -> 1 / ranks
+    calls = []
+    fake = type("S", (), {})()
+    fake._lib = type("L", (), {"call": staticmethod(lambda name, *a: calls.append((name, a)))})()
+    for attr in ("flat_p", "flat_g", "exp_avg", "exp_avg_sq"):
+        setattr(fake, attr, torch.zeros(4))
+    fake.state = torch.zeros(2, dtype=torch.int64)
+    fake.count, fake.lr, fake.wd, fake.BETAS, fake.EPS = 4, 1e-3, 0.0, (0.9, 0.999), 1e-8
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda: type("St", (), {"cuda_stream": 0})())
+    harness.NativeTrainStep._adam(fake)
+    harness.NativeTrainStep._adam(fake, 1.0)
+    assert [c[1][11] for c in calls] == [0.25, 1.0]
