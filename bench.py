@@ -119,10 +119,11 @@ def k8_roofline(model, x, batch, launches, storage="fp32"):
     xlin, s_i, s_j = ops.project_fwd(xs, gnn.lin.weight, c.terms)
     z = torch.empty_like(xlin)
     st = torch.cuda.current_stream().cuda_stream
+    nbr = c.graph.nbr_ordered()      # what ops.attn_aggregate_fwd hands the kernel when alpha is not asked for
 
     def k8(_i):
         _lib.call("gdn_attn_aggregate_fwd" + sfx, xlin.data_ptr(), s_i.data_ptr(), s_j.data_ptr(),
-                  c.graph.nbr.data_ptr(), c.graph.deg.data_ptr(), gnn.bias.data_ptr(),
+                  nbr.data_ptr(), c.graph.deg.data_ptr(), gnn.bias.data_ptr(),
                   batch, N_SENSORS, DIM, TOPK, z.data_ptr(), None, st)
 
     for i in range(3):
@@ -322,7 +323,9 @@ def run():
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="side streams the forward launches rotate over")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="side streams the forward launches of a step rotate over (matters with --coalesce 1: one launch "
+                         "per minibatch; a step that is ONE launch uses no side stream)")
     ap.add_argument("--exchange-chunk", type=int, default=32768,
                     help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
     ap.add_argument("--sweep-max", type=int, default=262144,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "gdn_forward_fused_plan": [_p, _p] + [_c_int] * 6 + [_p, _p, _p],
     "gdn_forward_fused_series_plan": [_p, _c_int, _c_int, _p] + [_c_int] * 5 + [_p, _p, _p],
     "gdn_fused_plan_limit_offset": [_c_int] * 5,
+    "gdn_graph_bank_order": [_p, _c_int, _c_int, _p, _p],
     "gdn_forward_fused_gated": [_p] * 12 + [_c_int] * 5 + [_p, _p],
     "gdn_forward_fused_series_gated": [_p, _p, _c_int, _c_int] + [_p] * 10 + [_c_int] * 5 + [_p, _p],
     "gdn_project_fwd_wide": [_p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p],

@@ -499,6 +499,61 @@ __global__ __launch_bounds__(64 * NT) void gdn_dense_plan_kernel(const DArgs a, 
   if (threadIdx.x == 0) plan[K::LIMIT_WORD] = __float_as_uint(xlim);
 }
 
+#ifndef GDN_DENSE_EXTRA_DC
+// The same greedy as gdn_dense_plan_kernel, but producing a reordered COPY OF THE LISTS: row i of `out` holds the
+// entries of row i of `nbr`, permuted inside each half (slots [0, SL) and [SL, 2 SL): the two lanes that share a
+// target) so that step q of the 32 lanes of a half-wave spreads over the LDS banks in the s_j gather and in the
+// two scatters.  The staged kernels (gdn_dense_attn_kernel, gdn_dense_project has no lists) read their lists from
+// whatever table they are given, and softmax / aggregation do not depend on the order of a target's slots, so a
+// caller that does not need alpha in rank order hands them this table (the fused kernel gets the same order from
+// its plan).  The bank of a slot depends on NT only: OFF_SJ is a multiple of 128 bytes in both kernels' LDS plans,
+// an image row starts (lane >> 1) * (16 NT + 4) dwords into a wave's block and a wave's block is a multiple of
+// 128 bytes.  One workgroup of 64 NT threads.
+template <int NT, int SL>
+__global__ __launch_bounds__(64 * NT) void gdn_bank_order_kernel(const uint16_t* __restrict__ nbr, int n, int pitch,
+                                                                 uint16_t* __restrict__ out) {
+  constexpr int T = 64 * NT;
+  __shared__ unsigned short s_j[T][SL];
+  __shared__ unsigned char s_perm[T][SL];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ti = 32 * wv + (lane >> 1), half = lane & 1;
+  const uint16_t* row = nbr + (size_t)min(ti, n - 1) * pitch + half * SL;
+#pragma unroll
+  for (int q = 0; q < SL; ++q) s_j[tid][q] = ti < n ? row[q] : (unsigned short)n;
+  __syncthreads();
+  if ((tid & 31) == 0) {
+    unsigned used[32];
+    for (int l = 0; l < 32; ++l) used[l] = 0;
+    for (int step = 0; step < SL; ++step) {
+      unsigned char cw[32], cr[32];
+      for (int i = 0; i < 32; ++i) cw[i] = cr[i] = 0;
+      for (int l = 0; l < 32; ++l) {
+        const int rowdw = (((tid + l) & 63) >> 1) * (16 * NT + 4);
+        int best = -1, best_cost = 1 << 30;
+        for (int q = 0; q < SL; ++q) {
+          if (used[l] >> q & 1u) continue;
+          const int j = s_j[tid + l][q];
+          const int bw = (rowdw + (pos_of_source(j) >> 1)) & 31, br = j & 31;
+          const int cost = 2 * (cw[bw] >= 1 ? 1 + 4 * (cw[bw] - 1) : 0) + (cr[br] >= 1 ? 1 + 4 * (cr[br] - 1) : 0);
+          if (cost < best_cost) { best_cost = cost; best = q; }
+        }
+        used[l] |= 1u << best;
+        s_perm[tid + l][step] = (unsigned char)best;
+        const int jb = s_j[tid + l][best];
+        ++cw[(rowdw + (pos_of_source(jb) >> 1)) & 31];
+        ++cr[jb & 31];
+      }
+    }
+  }
+  __syncthreads();
+  if (ti < n) {
+    uint16_t* dst = out + (size_t)ti * pitch + half * SL;
+#pragma unroll
+    for (int q = 0; q < SL; ++q) dst[q] = s_j[tid][s_perm[tid][q]];
+  }
+}
+#endif
+
 #ifdef GDN_DENSE_EXTRA_DC   // d = 128: one workgroup per CU and the whole 512-register file per wave (the default
 #define GDN_FUSED_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))   // heuristic keeps 2 waves/SIMD where LDS allows, and spills)
 #else
@@ -1551,7 +1606,15 @@ int fused_op(int op, const DArgs& a, unsigned* plan_out, long long* bytes, hipSt
   }
   auto kern = gdn_dense_fused_kernel<NT, DC, WK, SL, FMT>;
   const int occ = blocks_per_cu(reinterpret_cast<const void*>(kern), C::THREADS, C::LDS);
-  const int grid = max(1, min(a.batch, cu_count() * occ));
+  // A launch that cannot fill the machine twice over (one minibatch of 512 windows on 256 CUs) gets TWO windows
+  // per workgroup instead of one: every workgroup pays the prologue (~3 us: 90 plan words per lane, the zero
+  // fill), and the CU slots the thinner grid leaves free are what a concurrent launch on another stream runs
+  // in.  Measured at 512-window launches (bench.py --coalesce 1): one stream 46.6 -> 45.1 M windows/s, two
+  // streams 60.0 -> 71.3 M.  GDN_DENSE_MIN_WPW overrides (A/B runs; read once per process).
+  const int slots = cu_count() * occ;
+  int wpw = GDN_ENV_INT_ONCE("GDN_DENSE_MIN_WPW", 0);
+  if (wpw <= 0) wpw = (a.batch > cu_count() && a.batch <= slots) ? 2 : 1;
+  const int grid = max(1, min((a.batch + wpw - 1) / wpw, slots));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS, stream, a);
   return gdn_launch_status();
 }
@@ -1732,6 +1795,33 @@ extern "C" int gdn_debug_read_stamps(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dense_stamps), sizeof(g_dense_stamps)) == hipSuccess ? 0 : -2;
 }
 #endif
+
+// ---- bank-ordered neighbour lists (C ABI: include/gdn_hip.h) -------------------------------------------
+template <int NT>
+static int bank_order_select_sl(const uint16_t* nbr, int n, int pitch, uint16_t* out, hipStream_t st) {
+  switch (pitch) {
+    case 16: hipLaunchKernelGGL((gdn_bank_order_kernel<NT, 8>), dim3(1), dim3(64 * NT), 0, st, nbr, n, pitch, out); break;
+    case 32: hipLaunchKernelGGL((gdn_bank_order_kernel<NT, 16>), dim3(1), dim3(64 * NT), 0, st, nbr, n, pitch, out); break;
+    case 48: hipLaunchKernelGGL((gdn_bank_order_kernel<NT, 24>), dim3(1), dim3(64 * NT), 0, st, nbr, n, pitch, out); break;
+    case 64: hipLaunchKernelGGL((gdn_bank_order_kernel<NT, 32>), dim3(1), dim3(64 * NT), 0, st, nbr, n, pitch, out); break;
+    default: return GDN_ERR_UNSUPPORTED;
+  }
+  return gdn_launch_status();
+}
+
+extern "C" int gdn_graph_bank_order(const uint16_t* nbr, int n, int k, uint16_t* nbr_ordered, void* stream) {
+  if (!nbr || !nbr_ordered || n <= 0 || k <= 0) return GDN_ERR_ARG;
+  if (!gdn_dense_supported(n, 1, 64, k)) return GDN_ERR_UNSUPPORTED;
+  const int pitch = gdn_nbr_pitch(k);
+  hipStream_t st = (hipStream_t)stream;
+  switch ((n + 1 + 31) / 32) {
+    case 1: return bank_order_select_sl<1>(nbr, n, pitch, nbr_ordered, st);
+    case 2: return bank_order_select_sl<2>(nbr, n, pitch, nbr_ordered, st);
+    case 3: return bank_order_select_sl<3>(nbr, n, pitch, nbr_ordered, st);
+    case 4: return bank_order_select_sl<4>(nbr, n, pitch, nbr_ordered, st);
+  }
+  return GDN_ERR_UNSUPPORTED;
+}
 
 // ---- plans (C ABI: include/gdn_hip.h) -----------------------------------------------------------------
 extern "C" long long gdn_fused_plan_bytes(int n, int w, int d, int k, int bf16_storage) {

@@ -473,8 +473,9 @@ class GDN(nn.Module):
                 return out
             wide = self._wide_for(x)
             xlin, s_i, s_j = ops.project_fwd(x, gnn.lin.weight, c.terms, wide=wide)
-            z, alpha = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=True, wide=wide)
-            layer._set_dense((alpha, c.graph, batch))
+            # (alpha only on request — att_weight_1 — like the fused path: the launch then reads the bank-ordered lists)
+            z, _ = ops.attn_aggregate_fwd(xlin, s_i, s_j, c.graph, gnn.bias, batch, want_alpha=False, wide=wide)
+            layer._set_dense(lambda: self._dense_attention(x, c, batch))
             # out_layer_num > 1: the head kernel hands its [BN,d] activation to the OutLayer MLP
             # (plain library GEMMs through torch); its own Linear(d->1) result is unused here
             zero_w = torch.zeros((emb.shape[1],), device=x.device)

@@ -43,6 +43,20 @@ class SensorGraph:
         self.n, self.k = topk.shape
         self.pitch = nbr.shape[1]
         self._reverse = None
+        self._ordered = False       # not built yet; None = shape outside the matrix-core kernels
+
+    def nbr_ordered(self):
+        """The neighbour lists with every row permuted inside its two halves for LDS bank spread
+        (gdn_graph_bank_order), or `nbr` itself for shapes the matrix-core kernels do not take.  For launches
+        that do not hand alpha out in rank order.  Built on first use, once per graph."""
+        if self._ordered is False:
+            self._ordered = None
+            if self.n <= 127 and nbr_pitch(self.k) <= 64:
+                out = torch.empty_like(self.nbr)
+                out.copy_(self.nbr)                         # (padding rows / slots as in the original)
+                _lib.call("gdn_graph_bank_order", _ptr(self.nbr), self.n, self.k, _ptr(out), _stream())
+                self._ordered = out
+        return self.nbr if self._ordered is None else self._ordered
 
     def reverse(self):
         """(rent[n, rpitch] u32, rlen[n] i32): per source, the (target << 16 | slot) entries that
@@ -129,7 +143,8 @@ def project_fwd(x, lin_w, terms, wide: bool = False):
 
 
 def attn_aggregate_fwd(xlin, s_i, s_j, graph: SensorGraph, bias, batch: int, want_alpha: bool, wide: bool = False):
-    """models/graph_layer.py:65-74,82-117 -> z[B*n,d] (+ dense alpha[B*n,pitch])."""
+    """models/graph_layer.py:65-74,82-117 -> z[B*n,d] (+ dense alpha[B*n,pitch]).  Without alpha the lists come
+    from the bank-ordered copy of the graph (same z; alpha, when asked for, is in rank order as documented)."""
     sfx = _storage(xlin, "xlin")
     if wide and not sfx:
         sfx = "_wide"
@@ -138,7 +153,8 @@ def attn_aggregate_fwd(xlin, s_i, s_j, graph: SensorGraph, bias, batch: int, wan
     n = bn // batch
     z = torch.empty_like(xlin)
     alpha = torch.empty((bn, graph.pitch), dtype=torch.float32, device=xlin.device) if want_alpha else None
-    _lib.call("gdn_attn_aggregate_fwd" + sfx, _ptr(xlin), _ptr(_chk(s_i)), _ptr(_chk(s_j)), _ptr(graph.nbr),
+    nbr = graph.nbr if (want_alpha or wide or d != 64) else graph.nbr_ordered()
+    _lib.call("gdn_attn_aggregate_fwd" + sfx, _ptr(xlin), _ptr(_chk(s_i)), _ptr(_chk(s_j)), _ptr(nbr),
               _ptr(graph.deg), _ptr(_chk(bias.detach())), batch, n, d, graph.k, _ptr(z), _ptr(alpha), _stream())
     return z, alpha
 

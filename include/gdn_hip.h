@@ -311,6 +311,14 @@ int gdn_forward_fused_series(const float* series, int series_len, int first, con
                              const float* bn2_affine, const float* out_w, const float* out_b,
                              int batch, int n, int w, int d, int k, float* out, void* stream);
 
+/* gdn_graph_bank_order: a copy of the neighbour lists with every row's entries permuted inside its two halves
+ * (slots [0, pitch/2) and [pitch/2, pitch)) so that the staged matrix-core kernels' per-slot LDS accesses (the
+ * s_j gather, the two scatters into the attention image) spread over the banks: softmax and aggregation do not
+ * depend on the order of a target's slots, so gdn_attn_aggregate_fwd[_bf16] may be given this table instead of
+ * `nbr` whenever the caller does not read alpha in rank order (z is the same to the summation order of the
+ * softmax denominator).  Matrix-core shapes only (n <= 127, k <= 63); once per graph, one small launch.      */
+int gdn_graph_bank_order(const uint16_t* nbr, int n, int k, uint16_t* nbr_ordered, void* stream);
+
 /* ---- plans: the fused forward with its per-launch constants precomputed -------------
  * For shapes on the matrix-core path (n <= 127, d = 64 or 128, w <= 32, k <= 63) everything a
  * workgroup of gdn_forward_fused derives from the parameters and the sensor graph (list

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 model = random_params(127, 15, 30, 64, seed=0).to(dev).eval()
 names = ["start", "consts loaded", "first x issued+barrier", "x stored", "B1 passed", "P done", "B2 passed",
          "S done", "M done", "E done + store", "kernel end"]
-for b in (512, 4096):
+for b in (512, 4096, 32768):
     x = torch.rand((b, 127, 15), device=dev)
     with torch.no_grad():
         for _ in range(50):
