@@ -326,6 +326,9 @@ def run():
     ap.add_argument("--streams", type=int, default=2,
                     help="side streams the forward launches of a step rotate over (matters with --coalesce 1: one launch "
                          "per minibatch; a step that is ONE launch uses no side stream)")
+    ap.add_argument("--sharded-graph", action="store_true",
+                    help="N>1: replay the ShardedEvaluator's compute segments from HIP graphs (measured slower than eager "
+                         "launches in the 1-rank rehearsal: 0.452 vs 0.426 ms)")
     ap.add_argument("--exchange-chunk", type=int, default=32768,
                     help="N>1: ticks per async all-to-all of the scoring keys (overlaps the following forward chunks)")
     ap.add_argument("--sweep-max", type=int, default=262144,
@@ -374,11 +377,13 @@ def run():
         # chunks.  No fallback: a rank that cannot build or run this step fails the whole job (a silently
         # different timed path would be reported under this path's label).
         total = t * world
-        sev = harness.ShardedEvaluator(model, x, y, total, chunk=args.exchange_chunk)
-        sev.step()
+        sev = harness.ShardedEvaluator(model, x, y, total, chunk=args.exchange_chunk, use_graph=args.sharded_graph)
+        sev.step()                      # eager: plans, constants, RCCL channels
+        sev.step()                      # captures the compute segments (or decides to stay eager)
         torch.cuda.synchronize()
         step = sev.step
-        step_impl = "ShardedEvaluator: eager launches, async all_to_all_single per chunk + one all_gather"
+        step_impl = ("ShardedEvaluator: compute segments replayed from HIP graphs" if sev._graphs is not None else
+                     "ShardedEvaluator: eager launches") + ", async all_to_all_single per chunk + one all_gather (eager RCCL)"
 
     # Kernel-level legs first, on every rank (their results are only reported by rank 0): K8 and fused
     # roofline with HIP events, each after its own ~60 ms of sustained launches.  Besides producing the

@@ -288,8 +288,9 @@ class ShardedEvaluator:
     `forward(start, stop)` must fill `self.pred[start:stop]`; the default runs the fused HIP forward."""
 
     def __init__(self, model, x_local, y_local: torch.Tensor, total_ticks: int, chunk: int = 4096,
-                 backend=HipScoreBackend, forward=None, group=None):
+                 backend=HipScoreBackend, forward=None, group=None, use_graph: bool = False):
         self.rank, self.size = world()
+        self.use_graph, self._graphs, self._warm, self._result = bool(use_graph), None, False, None
         self.group, self.backend, self.model = group, backend, model
         self.x, self.y, self.total = x_local, y_local, total_ticks
         self.t, self.n = y_local.shape
@@ -354,17 +355,20 @@ class ShardedEvaluator:
                 m.operand_range == "auto" and m.input_exceeds_limit(self.x))
         self.model.forward_into(self.x[start:stop], self.pred[start:stop], wide=self._wide)
 
-    def step(self):
-        works = []
-        for c in range(self.nchunks):
-            a, b = min(self.t, c * self.pitch), min(self.t, (c + 1) * self.pitch)
-            if b > a:
-                self.forward(a, b)
-                self.backend.keys(self.pred[a:b], self.y[a:b], self.pitch, out=self.send[c])
-            works.append(dist.all_to_all_single(self.recv[c].reshape(-1), self.send[c].reshape(-1),
-                                                self.out_sizes, self.in_sizes, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+    # A step = nchunks x [forward + keys of the chunk | async all-to-all of its key rows] -> [select of my sensors'
+    # median / IQR + my last 3 prediction rows into the published row] -> all-gather -> [median/IQR table, halo,
+    # smoothing + max].  The bracketed COMPUTE segments are plain launch sequences with static arguments: with
+    # `use_graph` each is captured once in a HIP graph and a step is nchunks + 2 replays and nchunks + 1
+    # collectives issued from Python — against ~10 launches per chunk before (a 0.35 ms GPU step does not survive
+    # ~100 us of Python per rank).  The collectives themselves stay eager: RCCL inside a captured graph is not
+    # something this one-GPU box can vouch for.
+    def _seg_forward(self, c):
+        a, b = min(self.t, c * self.pitch), min(self.t, (c + 1) * self.pitch)
+        if b > a:
+            self.forward(a, b)
+            self.backend.keys(self.pred[a:b], self.y[a:b], self.pitch, out=self.send[c])
+
+    def _seg_select(self):
         if self.n_mine:
             if self._sel_ws is not None:        # the select writes straight into the row this rank publishes
                 self.backend.select(self.recv.reshape(-1), self.nchunks * self.size, self.n_mine, self.pitch, self.total,
@@ -375,9 +379,9 @@ class ShardedEvaluator:
                 self.pub[: self.n_mine * 2] = mi.reshape(-1)
         if self.take:
             self.pub[self.cap * 2:].view(2, 3, self.n)[0, 3 - self.take:] = self.pred[self.t - self.take:]
-        dist.all_gather_into_tensor(self.gathered, self.pub, group=self.group)
+
+    def _seg_finish(self):
         torch.index_select(self.gathered, 0, self.mi_idx, out=self._med_iqr.view(-1))
-        med_iqr = self._med_iqr
         halo_p = halo_g = None
         if self.first_tick > 0:
             torch.index_select(self.gathered, 0, self.halo_idx.view(-1), out=self._halo64.view(-1))
@@ -386,7 +390,54 @@ class ShardedEvaluator:
         if self.t == 0:
             return torch.empty((0,), dtype=torch.float64, device=self.pred.device)
         extra = {"anomaly": self._anomaly} if self._anomaly is not None else {}
-        return self.backend.smooth_max(self.pred, self.y, med_iqr, self.first_tick, halo_p, halo_g, **extra)
+        return self.backend.smooth_max(self.pred, self.y, self._med_iqr, self.first_tick, halo_p, halo_g, **extra)
+
+    def _capture_segments(self):
+        """One eager step has run (plans, constants, RCCL channels are warm): capture the compute segments.  Returns
+        False (and stays eager) when anything about the capture fails."""
+        try:
+            torch.cuda.synchronize()
+            graphs = []
+            for fn, args in [(self._seg_forward, (c,)) for c in range(self.nchunks)] + [(self._seg_select, ()),
+                                                                                         (self._seg_finish, ())]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = fn(*args)
+                graphs.append(g)
+            self._graphs, self._result = graphs, out
+            return True
+        except Exception as exc:     # noqa: BLE001 — a capture that fails must not take the evaluator down with it
+            import warnings
+            warnings.warn(f"ShardedEvaluator: HIP-graph capture of the compute segments failed ({exc!r}); running eagerly")
+            self._graphs = None
+            torch.cuda.synchronize()
+            return False
+
+    def step(self):
+        graphs = self._graphs
+        if self.use_graph and graphs is None and self._warm:
+            self.use_graph = self._capture_segments()
+            graphs = self._graphs
+        works = []
+        for c in range(self.nchunks):
+            if graphs is not None:
+                graphs[c].replay()
+            else:
+                self._seg_forward(c)
+            works.append(dist.all_to_all_single(self.recv[c].reshape(-1), self.send[c].reshape(-1),
+                                                self.out_sizes, self.in_sizes, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if graphs is not None:
+            graphs[self.nchunks].replay()
+        else:
+            self._seg_select()
+        dist.all_gather_into_tensor(self.gathered, self.pub, group=self.group)
+        self._warm = True
+        if graphs is not None:
+            graphs[self.nchunks + 1].replay()
+            return self._result
+        return self._seg_finish()
 
 
 # --------------------------------------------------------------------------- resident-series evaluator

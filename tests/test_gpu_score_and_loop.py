@@ -204,7 +204,8 @@ def test_evaluator_replays_back_to_back_at_bench_size(gpu_device):
 def test_sharded_evaluator_one_rank_rccl_equals_series_evaluator(gpu_device):
     """harness.ShardedEvaluator (the N>1 eval step: per-chunk async all-to-all of the radix keys, blocked
     select over chunks*ranks row blocks, one all-gather) run with a 1-rank RCCL group on this GPU: same
-    predictions and anomaly scores as the single-GPU evaluator, also across repeated steps.  The
+    predictions and anomaly scores as the single-GPU evaluator, also across repeated steps, eagerly and with
+    the compute segments captured in HIP graphs (the collectives stay eager between the replays).  The
     multi-rank exchange logic itself is covered with gloo in tests/test_cpu_distributed.py."""
     import socket
     import torch.distributed as dist
@@ -223,13 +224,20 @@ def test_sharded_evaluator_one_rank_rccl_equals_series_evaluator(gpu_device):
         y = torch.rand((t, 127), generator=g).to(gpu_device)
         ref = harness.SeriesEvaluator(model, x, y, batch=512, use_graph=False, streams=1)
         want = ref.step().clone()
-        sev = harness.ShardedEvaluator(model, x, y, t, chunk=4096)
-        assert sev.nchunks == 3 and sev.pitch == 4096
-        for _ in range(3):
+        for use_graph in (False, True):
+            sev = harness.ShardedEvaluator(model, x, y, t, chunk=4096, use_graph=use_graph)
+            assert sev.nchunks == 3 and sev.pitch == 4096
+            for _ in range(4):                  # (use_graph: eager, capture + replay, replay, replay)
+                got = sev.step()
+            torch.cuda.synchronize()
+            # the compute segments replay from HIP graphs around the eager collectives
+            assert (sev._graphs is not None) == use_graph
+            assert torch.equal(sev.pred, ref.pred)
+            assert torch.equal(got, want)
+            sev.pred.zero_()                    # a replay really recomputes
             got = sev.step()
-        torch.cuda.synchronize()
-        assert torch.equal(sev.pred, ref.pred)
-        assert torch.equal(got, want)
+            torch.cuda.synchronize()
+            assert torch.equal(sev.pred, ref.pred) and torch.equal(got, want)
     finally:
         dist.destroy_process_group()
 
