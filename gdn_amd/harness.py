@@ -587,7 +587,7 @@ class AutogradTrainStep:
     """One optimisation step of the reference's train() (train.py:52-66: zero_grad, forward, MSE,
     backward, Adam) captured once in a HIP graph and replayed per minibatch — the form that goes through
     torch autograd and torch.optim.Adam(fused=True): used when `NativeTrainStep` does not apply
-    (out_layer_num > 1, a custom `model.dp` module).
+    (a custom `model.dp` module, an injected graph, an OutLayer or a shape the training kernels do not take).
 
     At the reference's batch sizes a step is ~30 launches of a few microseconds each, so issuing
     them from Python costs more than running them; a replayed graph removes that.  The graph

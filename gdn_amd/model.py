@@ -10,15 +10,18 @@ layout and initialisation stream); the arithmetic of the hot path runs in hand-w
 kernels reached through gdn_amd.ops -> libgdn_hip.so.  There is no CPU path: calling
 forward on CPU tensors raises.
 
-  eval, out_layer_num == 1 : one fused launch  x[B,N,W] -> out[B,N]       (ops.forward_fused)
-  eval, otherwise          : project -> attention/aggregate -> head kernels, OutLayer MLP
-                             through torch (plain library GEMMs)
-  train, out_layer_num == 1: project + attention/aggregate AND the BatchNorm/ReLU/embedding/
-                             dropout/Linear head run as HIP kernels forward and backward (the
-                             two autograd.Functions below); torch draws the dropout mask
-  train, otherwise         : the graph layer as above, BatchNorm statistics, dropout and the
-                             output MLP through torch ops
+  eval, out_layer_num == 1 : one fused launch  x[B,N,W] -> out[B,N]  (the planned matrix-core kernel, with the
+                             range guard: inputs beyond the 16-bit operand range are detected on the device
+                             and the launch is redone by the fp32 row-gather kernel — include/gdn_hip.h)
+  eval, otherwise          : project -> attention/aggregate -> head kernels, then the OutLayer MLP as ONE
+                             matrix-core launch (gdn_mlp_fwd; hidden > 256: torch's library GEMMs)
+  train, out_layer_num == 1: project + attention/aggregate AND the BatchNorm/ReLU/embedding/dropout/Linear
+                             head run as HIP kernels forward and backward (the autograd.Functions below)
+  train, otherwise         : the same, with the head passes ending at the dropped-out activation and the
+                             OutLayer MLP on the fp32 matrix cores (gdn_mlp_train_fwd/bwd; hidden not a
+                             multiple of 4 or > 256: torch ops)
                              (`loss.backward()` reaches every parameter exactly as in the reference)
+  harness.NativeTrainStep is the same arithmetic without autograd (flat buffers, in-kernel dropout, gdn_adam_step).
 """
 from __future__ import annotations
 

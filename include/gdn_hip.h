@@ -421,12 +421,13 @@ int gdn_forward_fused_series_plan_keys(const float* series, int series_len, int 
  * shape gdn_forward_fused takes: outside the matrix-core path the fp32 row-gather kernel
  * reads the bf16 windows and rounds its LDS-resident projected tile to bf16 (configs[4]:
  * 512 sensors, top-k 64, W = 30).
- * RANGE of the matrix-core kernels (fp32 and bf16 storage alike): operands travel as 16-bit
- * terms, x and the BatchNorm-folded features 8*(scale1*xlin + shift) must stay below 65504
- * in magnitude — true for the MinMax / standardised sensor data the reference trains on
- * (main.py:60-75); beyond it a 16-bit term overflows and the results are undefined (inf/NaN,
- * which the ReLUs may turn into 0).  GDN_FUSED_PATH=valu in the environment selects the fp32
- * row-gather kernels, which have fp32 range, for such data.                              */
+ * RANGE: with fp32 STORAGE the matrix-core kernels carry x, and the BatchNorm-folded features
+ * 8*(scale1*xlin + shift), as two f16 terms each: values of 65504 and beyond do not exist there.
+ * The reference takes any fp32 (models/graph_layer.py:56; its main.py normalises nothing, the
+ * offline scripts/process_*.py do), so see "range guard" above: planned launches detect
+ * out-of-range windows on the device, the `_wide` / `_gated` entry points are the fp32 row-gather
+ * kernels with fp32's own range.  With bf16 storage x is ONE exact bf16 term with fp32's exponent
+ * range and the projected tile is rounded to bf16: no such limit.                            */
 int gdn_project_fwd_bf16(const uint16_t* x, const float* lin_w, const float* node_terms,
                          int batch, int n, int w, int d,
                          uint16_t* xlin, float* s_i, float* s_j, void* stream);
