@@ -641,9 +641,12 @@ __device__ __forceinline__ void xflat_store(float* xs, int cnt, int w, float inv
   }
 }
 
+// Rows [r0, r1) of the window (the x tile in LDS holds exactly these rows, row r at xs[(r - r0) * XP]): the whole
+// window for the variants that stage it at once, one row chunk for the chunked variant (large n).
 template <int D, int MODE, int WPM>
 __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, float* smem, int b,
-                                             const float (&wb)[D / 32][WPM / 2]) {
+                                             const float (&wb)[D / 32][WPM / 2], int r0 = 0, int r1 = -1) {
+  if (r1 < 0) r1 = pl.n;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int lane = tid & 63, wv = tid >> 6, nw = nth >> 6;
   const int l32 = lane & 31, h = lane >> 5;
@@ -653,10 +656,10 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
   float* sj = smem + pl.off_sj;
   constexpr int XP = WPM + 1;
   // attention scalars: s = x_row . a + c[sensor]
-  for (int t = tid; t < pl.n; t += nth) {
+  for (int t = r0 + tid; t < r1; t += nth) {
     float pi = a.node_terms[2 * GDN_A_PITCH + t];
     float pj = a.node_terms[2 * GDN_A_PITCH + pl.n + t];
-    const float* xr = xs + t * XP;
+    const float* xr = xs + (t - r0) * XP;
 #pragma unroll
     for (int k = 0; k < WPM; ++k) {
       const float xv = xr[k];
@@ -675,9 +678,9 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
   // one wave per 32-row block (its A operand is loaded once and reused for every column block).
   // Measured alternative — dealing single 32x32 tiles round-robin so 8-wave workgroups stay busy —
   // was slower at n = 127 (A reloaded per tile): 48 vs 55 Mwin/s.
-  const int nrb = (pl.n + 31) >> 5;
-  for (int rb = wv; rb < nrb; rb += nw) {
-    const float* arow = xs + min(rb * 32 + l32, pl.n - 1) * XP + h;
+  const int nrb = (r1 + 31) >> 5;
+  for (int rb = (r0 >> 5) + wv; rb < nrb; rb += nw) {          // (r0 is a multiple of 32)
+    const float* arow = xs + (min(rb * 32 + l32, r1 - 1) - r0) * XP + h;
     float av[WPM / 2];
 #pragma unroll
     for (int kk = 0; kk < WPM / 2; ++kk) av[kk] = arow[2 * kk];
@@ -692,7 +695,7 @@ __device__ __forceinline__ void project_mfma(const Plan& pl, const Args& a, floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < pl.n) {
+        if (row < r1) {
           xl[row * D + cb * 32 + l32] = a.x_bf16 ? round_to_bf16(acc[r]) : acc[r];
           if constexpr (MODE == MODE_PROJECT)
             a.xlin_out[((size_t)b * pl.n + row) * pl.dfull + GDN_COL0(D) + cb * 32 + l32] = acc[r];
@@ -740,6 +743,65 @@ __device__ __forceinline__ void window_loop_mfma(const Plan& pl, const Args& a, 
     if constexpr (MODE == MODE_FUSED) aggregate_window<D, MODE, LST>(pl, a, smem, b);
     xflat_store<XU>(xs, cnt, pl.w, inv_w, XP, xr);
     __syncthreads();                                        // C: tile free, next x tile visible
+  }
+}
+
+// Large n (the 512-sensor stress shape): the projected tile alone takes 131 KB of LDS, the x tile of a whole window
+// (n x 33 floats = 68 KB) no longer fits beside it, and the VALU projection this kernel then fell back to was 60 %
+// of the fused launch (1.70 of 2.35 ms per 4096 windows, profiles/r03_kernels_config4_B4096_kernel_stats.csv).
+// Chunked form: the window's x values live in REGISTERS (XU per thread; a second set prefetches the next window),
+// the LDS x tile holds pl.xrows rows at a time (a multiple of 32: 160 rows = 21 KB at n = 512) and the matrix-core
+// projection runs chunk by chunk: [store chunk | barrier | s_i, s_j + MFMA of the chunk | barrier].
+template <int XU>
+__device__ __forceinline__ void xflat_store_rows(float* xs, int cnt, int w, float inv_w, int xp, int r0, int r1,
+                                                 const XFlat<XU>& r) {
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int t = threadIdx.x + u * blockDim.x;
+    const int row = (int)((t + 0.5f) * inv_w);   // exact for t < 2^16, w <= 64
+    if (t < cnt && row >= r0 && row < r1) xs[(row - r0) * xp + (t - row * w)] = r.v[u];
+  }
+}
+
+template <int D, int MODE, int WPM, int XU, int LST>
+__device__ __forceinline__ void window_loop_mfma_chunked(const Plan& pl, const Args& a, float* smem) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int l32 = tid & 31, h = (tid >> 5) & 1;
+  constexpr int XP = WPM + 1;
+  float* xs = smem + pl.off_xs;
+  const int rc = pl.xrows;                       // rows per chunk, a multiple of 32
+  for (int t = tid; t < rc * XP; t += nth) xs[t] = 0.f;     // pad columns w..WPM-1 are never written again
+  float wb[D / 32][WPM / 2];
+#pragma unroll
+  for (int cb = 0; cb < D / 32; ++cb)
+#pragma unroll
+    for (int kk = 0; kk < WPM / 2; ++kk) {
+      const int k = 2 * kk + h;
+      wb[cb][kk] = k < pl.w ? a.lin_w[(size_t)(GDN_COL0(D) + cb * 32 + l32) * pl.w + k] : 0.f;
+    }
+  const int cnt = pl.n * pl.w;
+  const float inv_w = 1.0f / (float)pl.w;
+  XFlat<XU> xcur, xnext;
+  const int row_stride = a.series_len > 0 ? a.series_len : pl.w;
+  const size_t win_stride = a.series_len > 0 ? 1 : (size_t)cnt;
+  const size_t first = a.series_len > 0 ? a.series_first : 0;
+  xflat_load<XU>(a, x_base(a, first + (size_t)blockIdx.x * win_stride), row_stride, cnt, pl.w, inv_w, xnext);
+  __syncthreads();   // zero fill done before the first store
+  for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
+    xcur = xnext;
+    const int nb = min(b + (int)gridDim.x, pl.batch - 1);   // last round: harmless re-read
+    xflat_load<XU>(a, x_base(a, first + (size_t)nb * win_stride), row_stride, cnt, pl.w, inv_w, xnext);   // lands under the math
+    for (int r0 = 0; r0 < pl.n; r0 += rc) {
+      const int r1 = min(pl.n, r0 + rc);
+      xflat_store_rows<XU>(xs, cnt, pl.w, inv_w, XP, r0, r1, xcur);
+      __syncthreads();                                      // chunk visible
+      project_mfma<D, MODE, WPM>(pl, a, smem, b, wb, r0, r1);
+      __syncthreads();                                      // chunk consumed (and, after the last one, the tile is ready)
+    }
+    if constexpr (MODE == MODE_FUSED) {
+      aggregate_window<D, MODE, LST>(pl, a, smem, b);
+      __syncthreads();                                      // tile free for the next window's projection
+    }
   }
 }
 
@@ -886,7 +948,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
       }
     }
   } else {
-    if constexpr (PROJ >= 2) {
+    if constexpr (PROJ == 5) {
+      static_assert(D >= 32, "MFMA projection needs d >= 32");
+      window_loop_mfma_chunked<D, MODE, 32, 32, LST>(pl, a, smem);
+      if constexpr (MODE == MODE_FUSED) gate_release(a);
+      return;
+    } else if constexpr (PROJ >= 2) {
       static_assert(D >= 32 || PROJ < 2, "MFMA projection needs d >= 32");
       window_loop_mfma<D, MODE, (PROJ == 4 ? 32 : 16), (PROJ == 2 ? 8 : 16), LST>(pl, a, smem);
       if constexpr (MODE == MODE_FUSED) gate_release(a);
@@ -1049,6 +1116,14 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
     const int need = base_bytes + xs_bytes;
     if (need <= LDS_MAX && n * w <= 16 * *threads) {
       pl->mfma = 1; pl->wpm = wpm; pl->xp = wpm + 1;
+    } else if (*threads == 512 && n * w <= 32 * 512) {
+      // chunked form (window_loop_mfma_chunked): x in registers, the LDS x tile holds a row chunk — as many 32-row
+      // blocks as fit beside the projected tile (512 sensors at d = 64: 160 rows)
+      const int rows = ((LDS_MAX - base_bytes) / (33 * 4)) & ~31;
+      if (rows >= 32) {
+        pl->mfma = 2; pl->wpm = 32; pl->xp = 33;
+        pl->xrows = rows < ((n + 31) & ~31) ? rows : ((n + 31) & ~31);
+      }
     }
   }
   if (!pl->mfma && mode != MODE_ATTN &&
@@ -1059,7 +1134,7 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
   pl->off_nbr = off;
   pl->off_xs = off;
   int fixed = off * 4;
-  const int xs_full = pl->mfma ? n * pl->xp * 4 : n * pl->wp * 4;
+  const int xs_full = pl->mfma == 2 ? pl->xrows * pl->xp * 4 : (pl->mfma ? n * pl->xp * 4 : n * pl->wp * 4);
   if (fixed > LDS_MAX) return GDN_ERR_UNSUPPORTED;
   // neighbour lists go to LDS when they fit beside the x tile (MFMA path: the whole window)
   int remaining = LDS_MAX - fixed;
@@ -1070,7 +1145,9 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
     remaining -= nbr_bytes;
   }
   if (mode != MODE_ATTN) {
-    if (xs_full <= remaining) {
+    if (pl->mfma == 2) {
+      remaining -= xs_full;                      // (xrows = the chunk, chosen above to fit)
+    } else if (xs_full <= remaining) {
       pl->xrows = n;
       remaining -= xs_full;
     } else {
@@ -1120,6 +1197,10 @@ int select_proj(const Plan& pl, const Args& a, int threads, hipStream_t st) {
     return select_maxr<D, MODE, NT, 1>(pl, a, st);
   } else {
     if constexpr (D >= 32) {
+      if (pl.mfma == 2) {      // chunked: x in registers, the LDS x tile one row chunk at a time (512 threads)
+        if constexpr (NT == 512) return select_maxr<D, MODE, NT, 5>(pl, a, st);
+        else return GDN_ERR_UNSUPPORTED;
+      }
       if (pl.mfma) {
         if (pl.wpm == 32) return select_maxr<D, MODE, NT, 4>(pl, a, st);
         if (pl.n * pl.w <= 8 * threads) return select_maxr<D, MODE, NT, 2>(pl, a, st);
