@@ -423,7 +423,11 @@ __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, 
   for (int v = 0; v < G::VEC; ++v) acc.v[v] = 0.f;
 
   if constexpr (MAXR > 0) {
-    const int nr = MAXR <= 2 ? MAXR : (pl.pitch >> 4);   // rounds in use (wave-uniform)
+    // rounds in use.  MAXR = 5: from the target's own degree — the pitch leaves room for k + 1 entries, but a
+    // sensor is (almost always) in its own top-k, so k = 64 fills exactly 4 rounds and the fifth holds sentinels
+    // only: skipping it is 20 % of the gather work of BASELINE configs[4].  (The four targets of a wave may in
+    // principle differ: the branch is then taken per 16-lane group.)
+    const int nr = MAXR <= 2 ? MAXR : min(pl.pitch >> 4, ((int)c.degs[i] + 15) >> 4);
     int jn[MAXR];
     float e[MAXR];
     float m = -INFINITY;
@@ -505,6 +509,8 @@ __device__ __forceinline__ void aggregate_target(const Plan& pl, const Args& a, 
             if (arow) arow[r * 16 + l16] = al;
           }
           gather_steps<D, 0, (MODE == MODE_ATTN ? GDN_GATHER_CHUNK_ATTN : GDN_GATHER_CHUNK)>(c.xl_lane, al, jn[r] * (D * 4), acc);
+        } else if constexpr (MODE == MODE_ATTN) {
+          if (arow && r * 16 < pl.pitch) arow[r * 16 + l16] = 0.f;      // a round of sentinels: weights 0
         }
       }
     }
@@ -568,6 +574,9 @@ __device__ __forceinline__ void aggregate_window(const Plan& pl, const Args& a, 
     out_b = blockIdx.y == 0 ? a.out_b[0] : 0.f;
   }
 
+  // (Measured, round 3: fetching the NEXT target's list entries and embedding row one target ahead at the 512-sensor
+  // shape changed nothing — 9.13 vs 9.34 ms per 32768 windows: the kernel is VALU-issue bound there,
+  // SQ_WAIT_INST_ANY 5 % of the wave cycles, profiles/r03_sq_counters_config4_B4096.json.)
   for (int i = slot; i < pl.n; i += tpp) {
     Pack<G::VEC> emb_i;
     if constexpr (MODE == MODE_FUSED) emb_i = ld_pack<G::VEC>(a.emb + (size_t)i * pl.dfull + gcol);
