@@ -549,6 +549,11 @@ class SeriesEvaluator:
         key = self.model._constants().key
         if key != getattr(self, "_graph_key", None):
             self.graph = self.fgraph = None
+            if getattr(self, "_graph_key", None) is not None:      # the x limit follows the parameters: look again
+                src0 = self.series if self.series is not None else self.x
+                m = self.model
+                self.wide = (m.operand_range == "wide" and src0.dtype != torch.bfloat16) or (
+                    m.operand_range == "auto" and m.out_layer_num == 1 and m.input_exceeds_limit(src0))
             self._graph_key = key
 
     def _capture(self, fn):
@@ -630,8 +635,12 @@ class AutogradTrainStep:
     # the two halves of a step; `loss` is written in place so it survives replays
     def _forward_backward(self):
         self.optimizer.zero_grad(set_to_none=True)      # backward then writes fresh gradients: no fill, no add
+        before = self.model.operand_range
         self.model.operand_range = "wide" if self.wide else "narrow"      # no host check inside a captured step
-        out = self.model(self.x, None)
+        try:
+            out = self.model(self.x, None)
+        finally:
+            self.model.operand_range = before
         if self._torch_mse:     # diagnostic (tools/probe_mse_replay.py): the round-1 form with torch's reduction
             loss = F.mse_loss(out, self.y, reduction="mean")
             loss.backward()

@@ -348,6 +348,11 @@ class GDN(nn.Module):
     def _guard(self, c, stream):
         """The int32[2] range guard of this stream (zero: the gated launch leaves it zeroed)."""
         g = c.guards.get(stream.cuda_stream)
+        if g is None and torch.cuda.is_current_stream_capturing():
+            # first use inside somebody's capture: no stream switch, no event — the zero fill becomes a node of that
+            # graph (every replay starts from a lowered guard, which is what the gated launch leaves anyway)
+            g = torch.zeros((2,), dtype=torch.int32, device=self.embedding.weight.device)
+            c.guards[stream.cuda_stream] = g
         if g is None:
             with torch.cuda.stream(c.stream) if c.stream is not None else contextlib.nullcontext():
                 g = torch.zeros((2,), dtype=torch.int32, device=self.embedding.weight.device)

@@ -434,3 +434,29 @@ def test_evaluator_and_training_on_raw_unit_series(gpu_device):
     # (logits are O(1e5) here: the softmax is one-hot and its gradient is what survives cancellation, so fp32 —
     # any fp32 — keeps 3 digits of the attention gradients, not 5: bounds widened accordingly)
     assert_grads_close(got, want, tol_max=1e-3, tol_elem=0.5, what="raw-unit training step")
+
+
+def test_range_guard_inside_a_user_captured_graph(gpu_device):
+    """A caller that captures `model(x)` in a HIP graph of their own (static input buffer) gets the guarded pair of
+    launches captured with it: replays on in-range and on raw-unit contents of the buffer both equal float64 — the
+    flag is raised and consumed on the device, nothing was decided at capture time."""
+    n, w, k, d, b = 127, 15, 30, 64, 16
+    model = random_params(n, w, k, d, seed=41)
+    p = {key: v.detach().clone() for key, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    g = torch.Generator().manual_seed(42)
+    static_x = torch.rand((b, n, w), generator=g).to(gpu_device)
+    with torch.no_grad():
+        model._constants()
+        model._plan(model._constants(), False)           # constants and plan exist before the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = model(static_x, None)
+    graph_nbr = model.learned_graph.cpu()
+    for scale in (1.0, 2.0e5, 1.0, 7.0e6):
+        x = torch.rand((b, n, w), generator=g) * scale
+        static_x.copy_(x.to(gpu_device))
+        graph.replay()
+        torch.cuda.synchronize()
+        _assert_fp32_grade(static_out, p, x, k, graph_nbr, what=f"captured, scale {scale}")
