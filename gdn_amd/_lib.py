@@ -37,6 +37,8 @@ SIGNATURES = {
     "gdn_mlp_train_workspace_bytes": [_c_int] * 4,
     "gdn_mlp_train_fwd": [_p] * 8 + [_c_int] * 4 + [_p] * 4,
     "gdn_mlp_train_bwd": [_p] * 4 + [_c_int] * 4 + [_p] * 7,
+    "gdn_mlp_eval_workspace_bytes": [_c_int] * 4,
+    "gdn_mlp_eval_fwd": [_p] * 6 + [_c_int] * 4 + [_p] * 3,
     "gdn_topk_graph_terms": [_p, _c_int, _c_int, _c_int] + [_p] * 8 + [_c_int, _p, _p],
     "gdn_forward_fused_plan_keys": [_p] * 4 + [_c_int] * 7 + [_p, _p],
     "gdn_forward_fused_series_plan_keys": [_p, _c_int, _c_int] + [_p] * 3 + [_c_int] * 6 + [_p, _p],

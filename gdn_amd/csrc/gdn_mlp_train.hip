@@ -216,25 +216,35 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
   const float bias_o = (MODE == CP_OUT) ? a.b_o[0] : 0.f;
   double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   double s_go = 0.0;
-  for (int m = blockIdx.x * slots + slot; m < a.rows; m += gridDim.x * slots) {
+  __shared__ float rowpart[4];                  // H > 256: a row spans two waves, their partial dot products meet here
+  // (uniform trip count: the CP_OUT row reduction of wide layers has a barrier inside the loop)
+  for (int mrow = blockIdx.x * slots; mrow < a.rows; mrow += gridDim.x * slots) {
+    const int m = mrow + slot;
+    const bool row_ok = m < a.rows;
     float y[4] = {0.f, 0.f, 0.f, 0.f}, act[4];
-    if (live) ldf4(a.Y + (size_t)m * a.H + c0, y);
+    if (live && row_ok) ldf4(a.Y + (size_t)m * a.H + c0, y);
 #pragma unroll
     for (int v = 0; v < 4; ++v) act[v] = fmaxf(fmaf(y[v], sc[v], sh[v]), 0.f);
     if constexpr (MODE == CP_OUT) {
       float part = 0.f;
 #pragma unroll
       for (int v = 0; v < 4; ++v) part = fmaf(act[v], wo[v], part);
-      for (int st = 1; st < lpr; st <<= 1) part += __shfl_xor(part, st);
-      if (lr == 0) a.out[m] = part + bias_o;
+      for (int st = 1; st < (lpr < 64 ? lpr : 64); st <<= 1) part += __shfl_xor(part, st);
+      if (lpr > 64) {                             // 128 lanes per row: waves 2 slot and 2 slot + 1
+        if ((tid & 63) == 0) rowpart[tid >> 6] = part;
+        __syncthreads();
+        part = rowpart[2 * slot] + rowpart[2 * slot + 1];
+        __syncthreads();
+      }
+      if (lr == 0 && row_ok) a.out[m] = part + bias_o;
     } else {
       float gsrc[4];
       float go = 0.f;
       if (a.dA) {
         gsrc[0] = gsrc[1] = gsrc[2] = gsrc[3] = 0.f;
-        if (live) ldf4(a.dA + (size_t)m * a.H + c0, gsrc);
+        if (live && row_ok) ldf4(a.dA + (size_t)m * a.H + c0, gsrc);
       } else {
-        go = a.d_out[m];
+        go = row_ok ? a.d_out[m] : 0.f;
 #pragma unroll
         for (int v = 0; v < 4; ++v) gsrc[v] = go * wo[v];
       }
@@ -257,9 +267,9 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           o[v] = sc[v] * (dyh[v] - ma[v] - yh[v] * mb[v]);   // BatchNorm backward, sc = gamma * rstd
-          s0[v] += (double)o[v];                             // d bias of the Linear (analytically 0)
+          if (row_ok) s0[v] += (double)o[v];                 // d bias of the Linear (analytically 0)
         }
-        if (live) *reinterpret_cast<float4*>(a.dY + (size_t)m * a.H + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (live && row_ok) *reinterpret_cast<float4*>(a.dY + (size_t)m * a.H + c0) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
   }
@@ -275,10 +285,10 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
         for (int v = 0; v < 4; ++v) red[slot * a.H + c0 + v] = src[qn][v];
       }
       __syncthreads();
-      if (tid < a.H) {
+      for (int c = tid; c < a.H; c += 256) {
         double t = 0.0;
-        for (int sl = 0; sl < slots; ++sl) t += red[sl * a.H + tid];
-        dst[(size_t)qn * a.H + tid] = t;
+        for (int sl = 0; sl < slots; ++sl) t += red[sl * a.H + c];
+        dst[(size_t)qn * a.H + c] = t;
       }
     }
     if constexpr (MODE == CP_BSTAT) {
@@ -374,7 +384,7 @@ constexpr int MLP_SPLIT_MAX = 64;
 
 bool mlp_train_shape_ok(int rows, int d_in, int hidden, int layers) {
   return rows > 1 && layers >= 2 && layers <= 8 && d_in % 4 == 0 && d_in >= 4 && d_in <= 256 &&
-         hidden % 4 == 0 && hidden >= 4 && hidden <= 256;
+         hidden % 4 == 0 && hidden >= 4 && hidden <= 512;      // (512 = the reference class's default inter_num)
 }
 
 int col_grid(int rows, int H) {
@@ -411,6 +421,20 @@ Layout make_layout(int rows, int d_in, int hidden, int layers) {
   L.ws_split = off; off += up((size_t)MLP_SPLIT_MAX * hidden * max_sz((size_t)d_in, (size_t)hidden) * 4);
   L.ws_total = off;
   return L;
+}
+
+// eval mode: BatchNorm constants from the RUNNING statistics: [sc | sh | mean | rstd] as the column passes expect
+__global__ void mlp_eval_consts_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps, int H,
+                                       float* __restrict__ consts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  const float rstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  const float sc = gamma[c] * rstd;
+  consts[c] = sc;
+  consts[H + c] = beta[c] - rm[c] * sc;
+  consts[2 * H + c] = rm[c];
+  consts[3 * H + c] = rstd;
 }
 
 template <bool A_KC, bool B_KC, int TR>
@@ -469,6 +493,51 @@ extern "C" int gdn_mlp_train_fwd(const float* act, const float* const* params, f
     hipLaunchKernelGGL(mlp_finish_fwd_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, partial, tiles_m,
                        hidden, (double)rows, p[2], p[3], eps[l], momentum[l], rm, rv,
                        batches ? batches[l] : nullptr, consts);
+    in = Y;
+    in_consts = consts;
+  }
+  ColArgs c = {};
+  c.Y = in; c.consts = in_consts; c.w_o = out_w; c.b_o = out_b; c.out = out; c.rows = rows; c.H = hidden;
+  hipLaunchKernelGGL((mlp_col_kernel<CP_OUT>), dim3(col_grid(rows, hidden)), dim3(256), 0, st, c);
+  return gdn_launch_status();
+}
+
+// Eval-mode OutLayer MLP (models/GDN.py:45-56 under model.eval()) on the kernels above, for the widths the
+// one-launch register-resident chain of gdn_mlp.hip does not take (hidden > 256): per hidden layer one fp32
+// matrix-core GEMM (+ bias), the BatchNorm (running statistics) + ReLU applied while the next GEMM stages its
+// operand, then the Linear(hidden -> 1) column pass.  workspace: two [rows, hidden] buffers + two constant rows.
+extern "C" long long gdn_mlp_eval_workspace_bytes(int rows, int d_in, int hidden, int layers) {
+  if (rows < 1 || !mlp_train_shape_ok(rows > 1 ? rows : 2, d_in, hidden, layers)) return 0;
+  const size_t y = ((size_t)rows * hidden * 4 + 255) & ~(size_t)255, cst = ((size_t)4 * hidden * 4 + 255) & ~(size_t)255;
+  return (long long)(2 * y + 2 * cst);
+}
+
+extern "C" int gdn_mlp_eval_fwd(const float* act, const float* const* params, const float* const* running,
+                                const float* eps, const float* out_w, const float* out_b, int rows, int d_in,
+                                int hidden, int layers, void* workspace, float* out, void* stream) {
+  if (!act || !params || !running || !eps || !out_w || !out_b || !workspace || !out || rows < 1) return GDN_ERR_ARG;
+  if (!mlp_train_shape_ok(rows > 1 ? rows : 2, d_in, hidden, layers)) return GDN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t y = ((size_t)rows * hidden * 4 + 255) & ~(size_t)255, cst = ((size_t)4 * hidden * 4 + 255) & ~(size_t)255;
+  char* ws = static_cast<char*>(workspace);
+  const float* in = act;
+  const float* in_consts = nullptr;
+  for (int l = 0; l + 1 < layers; ++l) {
+    const int K = l == 0 ? d_in : hidden;
+    float* Y = reinterpret_cast<float*>(ws + (size_t)(l & 1) * y);
+    float* consts = reinterpret_cast<float*>(ws + 2 * y + (size_t)(l & 1) * cst);
+    const float* const* p = params + 4 * l;
+    if (!p[0] || !p[1] || !p[2] || !p[3] || !running[2 * l] || !running[2 * l + 1]) return GDN_ERR_ARG;
+    GemmArgs g = {};
+    g.A = in; g.sam = K; g.sak = 1;
+    g.B = p[0]; g.sbk = 1; g.sbn = K;
+    g.C = Y; g.M = rows; g.N = hidden; g.K = K; g.kslice = (K + TK - 1) / TK * TK;
+    g.tr_sc = in_consts; g.tr_sh = in_consts ? in_consts + hidden : nullptr;
+    g.bias = p[1]; g.colstats = nullptr;
+    if (in_consts) launch_gemm<true, true, 1>(g, 1, st);
+    else launch_gemm<true, true, 0>(g, 1, st);
+    hipLaunchKernelGGL(mlp_eval_consts_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, p[2], p[3], running[2 * l],
+                       running[2 * l + 1], eps[l], hidden, consts);
     in = Y;
     in_consts = consts;
   }

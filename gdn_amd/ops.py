@@ -335,8 +335,8 @@ def mlp_train_layers(out_layer):
 
 
 def mlp_train_supported(out_layer, d_in: int, rows: int) -> bool:
-    """True when gdn_mlp_train_fwd/bwd take this OutLayer: 2..8 layers, d_in and hidden multiples of 4 up
-    to 256, every hidden layer of the same width."""
+    """True when gdn_mlp_train_fwd/bwd take this OutLayer: 2..8 layers, d_in (<= 256) and hidden (<= 512) multiples
+    of 4, every hidden layer of the same width."""
     parts = mlp_train_layers(out_layer)
     if parts is None:
         return False
@@ -345,6 +345,42 @@ def mlp_train_supported(out_layer, d_in: int, rows: int) -> bool:
     if any(lin.out_features != h for lin, _ in hidden) or hidden[0][0].in_features != d_in:
         return False
     return _lib.load().gdn_mlp_train_saved_bytes(rows, d_in, h, len(hidden) + 1) > 0
+
+
+def mlp_eval_wide_supported(out_layer, d_in: int) -> bool:
+    """True when gdn_mlp_eval_fwd takes this OutLayer (eval mode, hidden up to 512, multiples of 4, running
+    statistics tracked): the path for widths beyond the one-launch chain (mlp_plan / mlp_fwd: hidden <= 256)."""
+    parts = mlp_train_layers(out_layer)
+    if parts is None:
+        return False
+    hidden, _last = parts
+    h = hidden[0][0].out_features
+    if any(lin.out_features != h for lin, _ in hidden) or hidden[0][0].in_features != d_in:
+        return False
+    if any(bn.running_mean is None or not bn.track_running_stats for _lin, bn in hidden):
+        return False
+    return _lib.load().gdn_mlp_eval_workspace_bytes(2, d_in, h, len(hidden) + 1) > 0
+
+
+def mlp_eval_wide(h2, out_layer, out: torch.Tensor | None = None):
+    """h2[rows, d] -> out[rows]: OutLayer.forward (models/GDN.py:45-56) in eval mode on the fp32 matrix-core GEMM
+    kernels (gdn_mlp_eval_fwd)."""
+    h2 = _chk(h2, name="h2")
+    rows, d_in = h2.shape
+    hidden, last = mlp_train_layers(out_layer)
+    h, layers = hidden[0][0].out_features, len(hidden) + 1
+    ws = torch.empty((_lib.load().gdn_mlp_eval_workspace_bytes(rows, d_in, h, layers),), dtype=torch.uint8, device=h2.device)
+    if out is None:
+        out = torch.empty((rows,), dtype=torch.float32, device=h2.device)
+    params, running, eps = [], [], []
+    for lin, bn in hidden:
+        params += [_chk(lin.weight.detach()), _chk(lin.bias.detach()), _chk(bn.weight.detach()), _chk(bn.bias.detach())]
+        running += [_chk(bn.running_mean), _chk(bn.running_var)]
+        eps.append(float(bn.eps))
+    _lib.call("gdn_mlp_eval_fwd", _ptr(h2), _ptr_array(params), _ptr_array(running), (ctypes.c_float * len(eps))(*eps),
+              _ptr(_chk(last.weight.detach().reshape(-1))), _ptr(_chk(last.bias.detach().reshape(-1))),
+              rows, d_in, h, layers, _ptr(ws), _ptr(out), _stream())
+    return out
 
 
 def mlp_train_fwd(act, out_layer):

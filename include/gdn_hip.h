@@ -259,6 +259,17 @@ int gdn_mlp_train_bwd(const float* d_out, const float* act, const float* const* 
                       const void* saved, void* workspace, float* const* grads, float* d_out_w,
                       float* d_out_b, float* d_act, void* stream);
 
+/* gdn_mlp_eval_fwd: the OutLayer MLP under model.eval() (models/GDN.py:45-56: Linear, BatchNorm on the RUNNING
+ * statistics, ReLU per hidden layer, Linear(hidden -> 1)) for the widths the one-launch chain gdn_mlp_fwd does not
+ * take (hidden > 256; up to 512 = the reference class's default inter_num): one fp32 matrix-core GEMM per hidden
+ * layer, the BatchNorm + ReLU folded into the next GEMM's operand staging, a column pass for the last Linear.
+ * params / running as gdn_mlp_train_fwd (host arrays of device pointers; running must be non-null here).
+ * hidden and d_in multiples of 4; workspace: gdn_mlp_eval_workspace_bytes (0 = unsupported shape).          */
+long long gdn_mlp_eval_workspace_bytes(int rows, int d_in, int hidden, int layers);
+int gdn_mlp_eval_fwd(const float* act, const float* const* params, const float* const* running,
+                     const float* eps, const float* out_w, const float* out_b,
+                     int rows, int d_in, int hidden, int layers, void* workspace, float* out, void* stream);
+
 /* One launch less at the end of a training step: gdn_head_train_bwd_rng with (buffers_zeroed | 2) leaves out its
  * small finishing launch, gdn_project_bwd_partials is gdn_project_bwd without its reduce launch (*rows_out =
  * partial rows written to `workspace`), and gdn_train_finish runs both reductions as ONE launch (independent

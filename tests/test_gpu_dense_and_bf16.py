@@ -285,7 +285,11 @@ def test_bf16_staged_kernels_refuse_shapes_outside_the_matrix_core_path(gpu_devi
                                  dict(n=40, w=10, k=8, d=64, hidden=128, layers=3, b=33),
                                  dict(n=20, w=8, k=6, d=32, hidden=48, layers=2, b=5),
                                  dict(n=12, w=4, k=3, d=16, hidden=24, layers=4, b=70),
-                                 dict(n=30, w=20, k=10, d=128, hidden=200, layers=3, b=6)],
+                                 dict(n=30, w=20, k=10, d=128, hidden=200, layers=3, b=6),
+                                 # beyond the one-launch chain (hidden > 256): gdn_mlp_eval_fwd, fp32 matrix-core GEMMs;
+                                 # 512 = the default inter_num of the reference's OutLayer class (models/GDN.py:28)
+                                 dict(n=127, w=15, k=30, d=64, hidden=512, layers=2, b=9),
+                                 dict(n=27, w=10, k=8, d=64, hidden=384, layers=3, b=21)],
                          ids=lambda c: "n{n}_d{d}_h{hidden}_L{layers}".format(**c))
 def test_outlayer_mlp_on_the_matrix_cores(cfg, gpu_device):
     """out_layer_num > 1 in eval mode: gdn_mlp_fwd (one launch, activations in registers, BatchNorm folded into
@@ -307,7 +311,12 @@ def test_outlayer_mlp_on_the_matrix_cores(cfg, gpu_device):
     x = torch.rand((cfg["b"], cfg["n"], cfg["w"]), generator=g)
     with torch.no_grad():
         out = model(x.to(gpu_device), None)
-    assert model._constants().mlp is not None                     # the HIP kernel ran, not the library GEMMs
+    # a HIP kernel ran, not the library GEMMs: the one-launch chain up to 256 hidden units, gdn_mlp_eval_fwd beyond
+    from gdn_amd import ops
+    if cfg["hidden"] <= 256:
+        assert model._constants().mlp is not None
+    else:
+        assert model._constants().mlp is None and ops.mlp_eval_wide_supported(model.out_layer, cfg["d"])
     ref = gdn_oracle.forward(f64_params(p), x.double(), cfg["k"], cfg["layers"], graph=model.learned_graph.cpu())
     np.testing.assert_allclose(out.cpu().double().numpy(), ref["out"].numpy(), atol=2e-6, rtol=1e-5)
 

@@ -429,6 +429,7 @@ def test_native_step_is_refused_for_shapes_outside_the_training_kernels(gpu_devi
 
 # ---------------------------------------------------------------- train-mode OutLayer MLP (out_layer_num > 1)
 @pytest.mark.parametrize("rows,d_in,hidden,layers", [(60, 32, 48, 2), (60, 16, 24, 3), (4064, 64, 256, 2),
+                                                     (2033, 64, 512, 2), (517, 64, 384, 3), (130, 128, 260, 2),
                                                      (3456, 64, 128, 3), (1000, 128, 64, 4), (131, 64, 256, 2)])
 def test_mlp_train_kernels_match_fp64_autograd(rows, d_in, hidden, layers, gpu_device):
     """gdn_mlp_train_fwd / gdn_mlp_train_bwd (fp32 matrix cores, fp64 statistics) against the reference's
