@@ -138,3 +138,44 @@ def test_command_line_trains_and_reports(gpu_device, tmp_path, capsys, monkeypat
                      "-out_layer_inter_dim", "128"])
     assert 0.0 <= info[0] <= 1.0 and len(os.listdir(tmp_path / "pretrained" / "msl")) == 1
     assert "F1 score:" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("units", ["normalised", "raw"])
+def test_command_line_at_the_512_sensor_stress_shape(units, gpu_device, tmp_path, capsys, monkeypatch):
+    """BASELINE configs[4]'s width through the command line (HIP graph on by default: round 2 raised
+    GDN_ERR_UNSUPPORTED at the first batch): a synthetic 512-sensor series, top-k 64, W = 30, one epoch of the
+    native captured step, best-validation checkpoint, report printed.  `raw`: the same series in engineering units
+    (x 3e3: the reference's train() only checkpoints below a loss of 1e8, train.py:47) — the command line looks at its
+    resident series once and trains / evaluates on the fp32 row-gather kernels (include/gdn_hip.h "range guard")."""
+    import pandas as pd
+    from gdn_amd import main as cli
+    n, t_train, t_test = 512, 230, 120
+    rng = np.random.default_rng(3)
+    phase = rng.uniform(0, 6.28, size=n)
+    scale = 3.0e3 if units == "raw" else 1.0
+    def series(t0, t):
+        tt = np.arange(t0, t0 + t)[:, None]
+        return (0.5 + 0.4 * np.sin(0.07 * tt + phase[None, :]) + 0.02 * rng.standard_normal((t, n))) * scale
+    cols = [f"s{i}" for i in range(n)]
+    root = tmp_path / "data" / "wadi512"
+    os.makedirs(root)
+    pd.DataFrame(series(0, t_train), columns=cols).to_csv(root / "train.csv")
+    test = pd.DataFrame(series(t_train, t_test), columns=cols)
+    attack = np.zeros(t_test, dtype=int)
+    attack[60:80] = 1
+    test.iloc[60:80, :8] += 0.8 * scale
+    test["attack"] = attack
+    test.to_csv(root / "test.csv")
+    (root / "list.txt").write_text("\n".join(cols) + "\n")
+    monkeypatch.chdir(tmp_path)
+    from gdn_amd import harness
+    seen = []
+    real = harness.GraphedTrainStep
+    monkeypatch.setattr(harness, "GraphedTrainStep", lambda *a, **k: (seen.append(k.get("wide")), real(*a, **k))[1])
+    info = cli.main(["-dataset", "wadi512", "-data_root", str(tmp_path / "data"), "-batch", "32", "-slide_win", "30",
+                     "-dim", "64", "-slide_stride", "1", "-topk", "64", "-random_seed", "5", "-epoch", "1",
+                     "-val_ratio", "0.2", "-save_path_pattern", "wadi512"])
+    assert all(np.isfinite(v) for v in info[:3]) and 0.0 <= info[0] <= 1.0
+    assert len(os.listdir(tmp_path / "pretrained" / "wadi512")) == 1
+    assert "F1 score:" in capsys.readouterr().out
+    assert seen == [units == "raw"]              # the captured native step ran, on the kernels the data's range asks for
