@@ -322,6 +322,11 @@ __device__ __forceinline__ void gather_steps(const char* xl_lane, float al, int 
   }
 }
 
+// (Measured, round 3, at the 512-sensor shape — k = 64, where this loop is VALU-issue bound: handing the (weight,
+// row offset) pairs round through LDS instead of DPP — the lane group writes its 16 pairs, every lane reads pair S
+// back as a broadcast — was SLOWER: 11.7 ms per 32768 windows with the pair read right before its row fetch (two
+// chained LDS round trips per step), 10.4 ms with all 16 pairs preloaded by 8 ds_read_b128, against 9.1 ms for the
+// rotation below.)
 // Half a round (8 neighbours) at a time, software-pipelined by hand: the 8 LDS fetches of the NEXT
 // half are issued before the 16 packed FMAs of the current one (the machine scheduler left to itself
 // keeps only two fetches in flight).  S0 = first rotation step of the half (0 or 8).
