@@ -857,6 +857,9 @@ struct KArgs {
   float* alpha;            // [BN, pitch] or null
 };
 
+// (Measured, round 3: the bf16-storage variant compiles to 175 VGPRs — two waves per SIMD although its 51 KB of LDS
+// would allow three workgroups per CU.  Forcing three with the launch bound (168 VGPRs, 7 spilled) was SLOWER:
+// 281 vs 250 us per 32768 windows.  The kernel is bound by the LDS pipe, not by latency.)
 template <int NT, int SL, int FMT, bool WANT_ALPHA>
 __global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kernel(const KArgs a) {
   using C = KCfg<NT, SL, FMT>;
