@@ -110,7 +110,12 @@ struct BwdPlan {
 // other lanes of the SAME workgroup, a barrier in between).  Same arithmetic, same summation order.
 // DX = false: d_xlin is left to gdn_dense_attn_bwd_dx (the matrix-core form of pass 2); this kernel then
 // only sums d_s_j over the reverse lists in its second pass.
-template <int D, int NT, bool GLB, bool DX = true>
+// NSL > 1 (GLB only): a window's [n, D*NSL] tile does not fit LDS (512 sensors x 128 columns are 263 KB): the
+// workgroup walks NSL column slices of D one after the other, in both passes.  Pass 1 keeps the partial
+// d_alpha of the earlier slices in the d_pi workspace and finishes the softmax on the last slice (each
+// element is written and read back by the same lane); the sum of two slices is the sum the unsliced kernel
+// forms with its two lane groups, so both give the same bits.
+template <int D, int NT, bool GLB, bool DX = true, int NSL = 1>
 __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     const BwdPlan pl, const float* __restrict__ d_z, const float* __restrict__ xlin,
     const float* __restrict__ alpha, const float* __restrict__ s_i, const float* __restrict__ s_j,
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     float* __restrict__ d_bias, float* __restrict__ dpi_ws, float* __restrict__ bias_ws) {
   using G = GeoB<D>;
   constexpr int BL = 2048 / NT;
+  constexpr int DF = D * NSL;          // row stride of the global arrays
+  static_assert(NSL == 1 || (GLB && G::NS == 1), "column slices: tables in global memory, 64-column tiles");
   extern __shared__ float4 smem_b4[];
   float* smem = reinterpret_cast<float*>(smem_b4);
   float* tile = smem + pl.off_tile;    // xlin (pass 1) then d_z (pass 2); row n stays 0
@@ -134,18 +141,31 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
   const int rounds = pl.pitch >> 4;
   const int npl = pl.n * pl.pitch;
 
-  for (int t = tid; t < D; t += nth) {
-    dbias[t] = 0.f;
-    tile[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
-  }
+  for (int t = tid; t < DF; t += nth) dbias[t] = 0.f;
+  for (int t = tid; t < D; t += nth) tile[pl.n * D + t] = 0.f;   // sentinel row: read by padding slots, weight 0
   if (tid == 0) sj[pl.n] = 0.f;
   if constexpr (!GLB)
     for (int t = tid; t < npl / 2; t += nth)   // pitch is a multiple of 16: copy the lists as u32 pairs
       reinterpret_cast<uint32_t*>(smem + pl.off_nbr)[t] = reinterpret_cast<const uint32_t*>(nbr)[t];
-  PackB<G::VEC> bias_acc;
+  PackB<G::VEC> bias_acc[NSL];
 #pragma unroll
-  for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] = 0.f;
+  for (int s = 0; s < NSL; ++s)
+#pragma unroll
+    for (int v = 0; v < G::VEC; ++v) bias_acc[s].v[v] = 0.f;
   const int nvec = pl.n * D / 4;
+  // tile <- columns [c0, c0 + D) of the window's rows of `src` (row stride DF)
+  auto stage_tile = [&](const float* src, int c0) {
+    float4* dst = reinterpret_cast<float4*>(tile);
+    if constexpr (NSL == 1) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll 4
+      for (int t = tid; t < nvec; t += nth) dst[t] = s4[t];
+    } else {
+      const float4* s4 = reinterpret_cast<const float4*>(src + c0);
+#pragma unroll 4
+      for (int t = tid; t < nvec; t += nth) dst[t] = s4[(t / (D / 4)) * (DF / 4) + (t % (D / 4))];
+    }
+  };
 
   for (int b = blockIdx.x; b < pl.batch; b += gridDim.x) {
     const size_t row0 = (size_t)b * pl.n;
@@ -163,10 +183,7 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
       nb_l = reinterpret_cast<const uint16_t*>(smem + pl.off_nbr);
     }
     {   // bulk staging (many loads in flight): xlin tile, alpha table, s_i, s_j
-      const float4* src = reinterpret_cast<const float4*>(xlin + row0 * D);
-      float4* dst = reinterpret_cast<float4*>(tile);
-#pragma unroll 4
-      for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
+      stage_tile(xlin + row0 * DF, 0);
       if constexpr (!GLB) {
         const float4* asrc = reinterpret_cast<const float4*>(alpha + row0 * pl.pitch);
         float4* adst = reinterpret_cast<float4*>(smem + pl.off_al);
@@ -181,18 +198,26 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
     __syncthreads();
 
     // ---- pass 1: per target, BL targets per lane group at a time (their d_z rows are fetched together)
+#pragma unroll
+    for (int cs = 0; cs < NSL; ++cs) {
+    if (cs > 0) {        // next column slice of xlin
+      __syncthreads();
+      stage_tile(xlin + row0 * DF, cs * D);
+      __syncthreads();
+    }
+    const bool first = cs == 0, last = cs == NSL - 1;
     for (int ib = slot; ib < pl.n; ib += tpp * BL) {
       PackB<G::VEC> gq[BL];
 #pragma unroll
       for (int q = 0; q < BL; ++q)
-        gq[q] = ldp<G::VEC>(d_z + (row0 + min(ib + q * tpp, pl.n - 1)) * D + d0);
+        gq[q] = ldp<G::VEC>(d_z + (row0 + min(ib + q * tpp, pl.n - 1)) * DF + cs * D + d0);
 #pragma unroll
       for (int q = 0; q < BL; ++q) {
         const int i = ib + q * tpp;
         if (i >= pl.n) break;
         const PackB<G::VEC>& g = gq[q];
 #pragma unroll
-        for (int v = 0; v < G::VEC; ++v) bias_acc.v[v] += g.v[v];
+        for (int v = 0; v < G::VEC; ++v) bias_acc[cs].v[v] += g.v[v];
         const float sti = si[i];
         float dot = 0.f;
         for (int r = 0; r < rounds; ++r) {
@@ -201,9 +226,13 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
           float tsum = 0.f;
           dot_steps<D>(tile_lane, j * (D * 4), g, tsum);
           if constexpr (G::NS == 2) tsum += __shfl_xor(tsum, 16);
-          dot = fmaf(al_t[p], tsum, dot);
+          if constexpr (NSL > 1) {
+            if (!first) tsum += dpi_t[p];    // the earlier slices' share, written by this lane
+          }
+          if (last) dot = fmaf(al_t[p], tsum, dot);
           if (slice == 0) dpi_t[p] = tsum;   // d_alpha for now; finished below
         }
+        if (!last) continue;
         dot = row16_sum(dot);
         float dsi = 0.f;
         if (slice == 0) {
@@ -223,12 +252,12 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
         if (l16 == 0 && slice == 0) d_si[row0 + i] = dsi;
       }
     }
+    }
+#pragma unroll
+    for (int cs = 0; cs < NSL; ++cs) {
     __syncthreads();
-    if constexpr (DX) {   // the tile now holds d_z of this window (row n stays 0)
-      const float4* src = reinterpret_cast<const float4*>(d_z + row0 * D);
-      float4* dst = reinterpret_cast<float4*>(tile);
-#pragma unroll 4
-      for (int t = tid; t < nvec; t += nth) dst[t] = src[t];
+    if constexpr (DX) {   // the tile now holds (this column slice of) d_z of this window (row n stays 0)
+      stage_tile(d_z + row0 * DF, cs * D);
       __syncthreads();
     }
 
@@ -259,31 +288,35 @@ __global__ __launch_bounds__(NT) void gdn_attn_bwd_kernel(
           const bool valid = e < len;
           const uint32_t ent = r0 == 0 ? e0[q] : (r0 == 16 ? e1[q] : rrow[valid ? e : 0]);
           const int i = valid ? (int)(ent >> 16) : 0, p = valid ? (int)(ent & 0xffff) : 0;
-          dsj += valid ? dpi_t[i * pl.pitch + p] : 0.f;
+          if (cs == 0) dsj += valid ? dpi_t[i * pl.pitch + p] : 0.f;
           if constexpr (DX) {
             const float a = valid ? al_t[i * pl.pitch + p] : 0.f;
             axpy_steps<D>(tile_lane, a, (valid ? i : pl.n) * (D * 4), acc);
           }
         }
-        if constexpr (DX) stp<G::VEC>(d_xlin + (row0 + j) * D + d0, acc);
-        dsj = row16_sum(dsj);
-        if (l16 == 0 && slice == 0) d_sj[row0 + j] = dsj;
+        if constexpr (DX) stp<G::VEC>(d_xlin + (row0 + j) * DF + cs * D + d0, acc);
+        if (cs == 0) {
+          dsj = row16_sum(dsj);
+          if (l16 == 0 && slice == 0) d_sj[row0 + j] = dsj;
+        }
       }
+    }
     }
     __syncthreads();   // tables and tile are rewritten by the next window
   }
   // d_bias = column sums of d_z: the lane groups' sums meet in LDS in a fixed order (the tile is free by now),
   // the workgroups' rows in gdn_colsum_ticket — no floating-point atomics, bitwise reproducible
-  float* gsum = smem + pl.off_red;                      // [tpp][D] then nth floats (the tile itself when it is large enough)
-  stp<G::VEC>(gsum + slot * D + d0, bias_acc);
+  float* gsum = smem + pl.off_red;                      // [tpp][DF] then nth floats (the tile itself when it is large enough)
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) stp<G::VEC>(gsum + slot * DF + s * D + d0, bias_acc[s]);
   __syncthreads();
-  for (int t = tid; t < D; t += nth) {
+  for (int t = tid; t < DF; t += nth) {
     float s = 0.f;
-    for (int q = 0; q < tpp; ++q) s += gsum[q * D + t];
+    for (int q = 0; q < tpp; ++q) s += gsum[q * DF + t];
     dbias[t] = s;
   }
   __syncthreads();
-  gdn_colsum_ticket(bias_ws, dbias, D, d_bias, gsum + tpp * D);
+  gdn_colsum_ticket(bias_ws, dbias, DF, d_bias, gsum + tpp * DF);
 }
 
 // Reverse lists: for source j, the (target i, slot p) pairs with nbr[i][p] == j, in ascending i
@@ -530,12 +563,14 @@ extern "C" int gdn_graph_reverse(const uint16_t* nbr, const int32_t* deg, int n,
   return gdn_launch_status();
 }
 
-// LDS plan of the backward: with_tables = the two [n, pitch] tables and the lists sit beside the tile
-static bool bwd_plan(int batch, int n, int d, int k, bool with_tables, BwdPlan* pl) {
+// LDS plan of the backward: with_tables = the two [n, pitch] tables and the lists sit beside the tile;
+// td = columns of the tile (d, or 64 when the kernel walks column slices)
+static bool bwd_plan(int batch, int n, int d, int k, bool with_tables, BwdPlan* pl, int td = 0) {
+  if (td <= 0) td = d;
   pl->n = n; pl->d = d; pl->k = k; pl->batch = batch; pl->pitch = gdn_nbr_pitch(k); pl->rpitch = gdn_rev_pitch(n);
   const int npad = (n + 1 + 3) & ~3;   // +1: the sentinel index n used as list padding
   int off = 0;
-  pl->off_tile = off; off += (n + 1) * d;
+  pl->off_tile = off; off += (n + 1) * td;
   pl->off_sj = off; off += npad;
   pl->off_si = off; off += npad;
   pl->off_al = off; off += with_tables ? n * pl->pitch : 0;
@@ -544,12 +579,15 @@ static bool bwd_plan(int batch, int n, int d, int k, bool with_tables, BwdPlan* 
   pl->off_nbr = off; off += with_tables ? n * pl->pitch / 2 : 0;   // u16 lists
   // end-of-kernel d_bias reduction: [lane groups <= 32][d] partial rows + one float per thread (<= 512); it
   // borrows the tile when that is large enough (every window is done by then)
-  const int red = 32 * (d < 64 ? d : 64) + 512;
-  if ((n + 1) * d >= red) pl->off_red = pl->off_tile;
+  const int red = 32 * (td < d ? d : (d < 64 ? d : 64)) + 512;
+  if ((n + 1) * td >= red) pl->off_red = pl->off_tile;
   else { pl->off_red = off; off += red; }
   pl->lds_bytes = off * 4;
   return pl->lds_bytes <= 160 * 1024;
 }
+
+// GDN_BWD_SLICED=1 (read once per process): d = 128 always walks two 64-column slices (A/B against the whole tile)
+static bool gdn_bwd_sliced_forced() { return GDN_ENV_INT_ONCE("GDN_BWD_SLICED", 0) != 0; }
 
 // workspace = [ticket + GDN_COLSUM_MAX_ROWS partial rows of d_bias][d_pi tables when they do not fit LDS]
 static long long bwd_bias_ws_floats(int d) { return GDN_COLSUM_WS_HEAD + (long long)GDN_COLSUM_MAX_ROWS * d; }
@@ -558,7 +596,8 @@ extern "C" long long gdn_attn_aggregate_bwd_workspace_bytes(int batch, int n, in
   if (batch <= 0 || n <= 0 || k <= 0 || k > n || d <= 0) return 0;
   BwdPlan pl;
   long long floats = bwd_bias_ws_floats(d);
-  if (!bwd_plan(batch, n, d, k, true, &pl)) floats += (long long)batch * n * gdn_nbr_pitch(k);   // tables beyond LDS
+  if (!bwd_plan(batch, n, d, k, true, &pl) || (d == 128 && gdn_bwd_sliced_forced()))
+    floats += (long long)batch * n * gdn_nbr_pitch(k);   // tables beyond LDS
   return floats * (long long)sizeof(float);
 }
 
@@ -588,11 +627,18 @@ static int attn_aggregate_bwd_impl(const float* d_z, const float* xlin, const fl
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   if (k > n || n > 4096 || k + 1 > 1024) return GDN_ERR_UNSUPPORTED;
   BwdPlan pl;
-  bool glb = false;
-  if (!bwd_plan(batch, n, d, k, true, &pl)) {
-    // tables through global memory (the workspace behind the d_bias rows); the tile alone must still fit
-    if (!bwd_plan(batch, n, d, k, false, &pl)) return GDN_ERR_UNSUPPORTED;
+  bool glb = false, sliced = false;
+  if (gdn_bwd_sliced_forced() && d == 128) {
+    if (!bwd_plan(batch, n, d, k, false, &pl, 64)) return GDN_ERR_UNSUPPORTED;
+    glb = sliced = true;
+  } else if (!bwd_plan(batch, n, d, k, true, &pl)) {
+    // tables through global memory (the workspace behind the d_bias rows); the tile alone must still fit,
+    // whole or (d = 128) as two 64-column slices the workgroup walks one after the other
     glb = true;
+    if (!bwd_plan(batch, n, d, k, false, &pl)) {
+      if (d != 128 || !bwd_plan(batch, n, d, k, false, &pl, 64)) return GDN_ERR_UNSUPPORTED;
+      sliced = true;
+    }
   }
   hipStream_t st = (hipStream_t)stream;
   float* dpi_ws = workspace + bwd_bias_ws_floats(d);
@@ -613,6 +659,13 @@ static int attn_aggregate_bwd_impl(const float* d_z, const float* xlin, const fl
     else if (many_rows) GDN_BWD_NT(DD, 512, false)                         \
     else GDN_BWD_NT(DD, 256, false)                                   \
     break;
+  if (sliced) {
+    const int grid = min(occupancy_grid(gdn_attn_bwd_kernel<64, 512, true, true, 2>, 512, pl.lds_bytes, batch),
+                         GDN_COLSUM_MAX_ROWS);
+    hipLaunchKernelGGL((gdn_attn_bwd_kernel<64, 512, true, true, 2>), dim3(grid), dim3(512), pl.lds_bytes, st, pl,
+                       d_z, xlin, alpha, s_i, s_j, nbr, rent, rlen, d_xlin, d_si, d_sj, d_bias, dpi_ws, workspace);
+    return gdn_launch_status();
+  }
   switch (d) {
     GDN_BWD(16)
     GDN_BWD(32)
@@ -648,7 +701,9 @@ extern "C" int gdn_train_supported(int n, int w, int d, int k) {
   if (n <= 0 || w <= 0 || k <= 0 || k > n || n > 4096 || k + 1 > 1024 || w > GDN_MAX_W) return 0;
   if (d != 16 && d != 32 && d != 64 && d != 128) return 0;
   BwdPlan pl;
-  if (!bwd_plan(1, n, d, k, true, &pl) && !bwd_plan(1, n, d, k, false, &pl)) return 0;
+  if (!bwd_plan(1, n, d, k, true, &pl) && !bwd_plan(1, n, d, k, false, &pl) &&
+      !(d == 128 && bwd_plan(1, n, d, k, false, &pl, 64)))
+    return 0;
   const int wp = w <= 8 ? 8 : ((w + 15) & ~15);
   int rc = (24576 - 2 * n) / (wp + d + 2);                  // gdn_project_bwd's staging chunk
   if (rc < 1) return 0;

@@ -26,7 +26,8 @@
  *   backward (gdn_attn_aggregate_bwd): that tile at full d PLUS two [n, pitch] fp32 tables and the lists
  *     in LDS — n up to ~250 at d = 64 with k = 30 (127-sensor WADI, 51-sensor SWaT, the 25-55-sensor
  *     MSL/SMAP/PSM sets); beyond that the tables go through the caller's workspace in global memory and
- *     only the tile must fit (n <= ~600 at d = 64: the 512-sensor / k = 64 stress shape trains);
+ *     only the tile must fit (n <= ~600 at d = 64: the 512-sensor / k = 64 stress shape trains; d = 128 walks
+ *     two 64-column slices when the full tile does not fit: n <= ~600 there too);
  *   matrix-core ("dense") kernels — gdn_forward_fused, gdn_project_fwd, gdn_attn_aggregate_fwd pick them
  *     by themselves for n <= 127, d = 64, w <= 32, k <= 63 (gdn_forward_fused also at d = 128); the staged
  *     bf16-storage entry points exist only there;

@@ -371,10 +371,13 @@ def test_native_step_state_follows_checkpoint_round_trip(gpu_device):
         assert torch.equal(model(x, None), fresh(x, None))
 
 
+@pytest.mark.parametrize("n,k,d", [(512, 64, 64), (512, 64, 128), (400, 20, 128)])
 @pytest.mark.parametrize("path", ["autograd", "native_graph"])
-def test_training_step_at_the_512_sensor_stress_shape(path, gpu_device):
+def test_training_step_at_the_512_sensor_stress_shape(path, n, k, d, gpu_device):
     """BASELINE configs[4] shape (512 sensors, top-k 64, W=30, d=64): the backward's two [n, pitch] tables
     (164 KB each) cannot sit in LDS, gdn_attn_aggregate_bwd runs them through its workspace in global memory.
+    At d = 128 a window's [n, 128] tile (263 KB) does not fit either: the workgroup walks two 64-column slices
+    (round 2 and the first half of round 3 refused the shape).
     One training step against float64 (loss and every gradient, relative bounds), through the autograd
     Functions and through the DEFAULT path of harness.train / python -m gdn_amd.main: the captured
     NativeTrainStep (round 2 raised GDN_ERR_UNSUPPORTED there).  The reference trains at any n
@@ -382,7 +385,7 @@ def test_training_step_at_the_512_sensor_stress_shape(path, gpu_device):
     from gdn_amd import harness
     from _grad_check import KINK_BAND, assert_grads_close, oracle_step
     from test_gpu_forward_parity import random_params
-    n, w, k, d, b = 512, 30, 64, 64, 2
+    w, b = 30, 2
     model = random_params(n, w, k, d, seed=21)
     p = {key: v.detach().clone() for key, v in model.state_dict().items()}
     model = model.to(gpu_device).train()
@@ -410,7 +413,7 @@ def test_training_step_at_the_512_sensor_stress_shape(path, gpu_device):
         graph = step.ws["topk"].cpu()
     ref_loss, want, kink = oracle_step(p, x, y, graph, 1, mask)
     assert kink > KINK_BAND
-    assert abs(float(loss) - ref_loss) < 2e-6
+    assert abs(float(loss.detach()) - ref_loss) < 2e-6
     assert_grads_close(got, want, what=path)
 
 
@@ -420,6 +423,8 @@ def test_native_step_is_refused_for_shapes_outside_the_training_kernels(gpu_devi
     from gdn_amd import _lib, harness
     from test_gpu_forward_parity import random_params
     assert _lib.load().gdn_train_supported(512, 30, 64, 64) == 1
+    assert _lib.load().gdn_train_supported(512, 30, 128, 64) == 1          # two column slices
+    assert _lib.load().gdn_train_supported(1024, 30, 128, 64) == 0         # a 64-column slice is beyond LDS too
     assert _lib.load().gdn_train_supported(127, 15, 64, 30) == 1
     assert _lib.load().gdn_train_supported(2000, 15, 64, 30) == 0          # (n+1)*d*4 > 160 KB
     assert _lib.load().gdn_train_supported(127, 15, 48, 30) == 0           # d outside {16, 32, 64, 128}
