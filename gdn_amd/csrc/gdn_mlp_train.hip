@@ -41,6 +41,8 @@ struct GemmArgs {
   const float* tr_sc; const float* tr_sh;   // relu(v*sc[c] + sh[c]) applied to an operand while staging it
   const float* bias;                    // [N] added in the epilogue, or null
   double* colstats;                     // [tiles_m][2][N]: per row-tile column sums of C and C^2, or null
+  int vec;                              // 1: every extent along a contiguous direction is a multiple of 4 (float4
+                                        // staging loads); 0: element loads with their own bounds (odd hidden widths)
 };
 
 // A_KC: A is contiguous along k (else along m).  B_KC: B is contiguous along k (else along n).
@@ -64,9 +66,23 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const GemmArgs g) {
   const int b_r = B_KC ? (tid >> 2) : ((tid & 15) * 4);   // n
   const int b_k = B_KC ? ((tid & 3) * 4) : (tid >> 4);
 
+  static_assert(TR != 1 || A_KC, "the A transform is indexed by k along the staged quad");
+  static_assert(TR != 2 || !B_KC, "the B transform is indexed by n along the staged quad");
   auto load_a = [&](int k0) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int m = m0 + a_r, k = k0 + a_k;
+    if (!g.vec) {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mm = A_KC ? m : m + q, kk = A_KC ? k + q : k;
+        if (mm < g.M && kk < kend) {
+          e[q] = g.A[(long long)mm * g.sam + (long long)kk * g.sak];
+          if constexpr (TR == 1) e[q] = fmaxf(fmaf(e[q], g.tr_sc[kk], g.tr_sh[kk]), 0.f);
+        }
+      }
+      return make_float4(e[0], e[1], e[2], e[3]);
+    }
     if (m < g.M && k < kend) {
       if constexpr (A_KC) v = *reinterpret_cast<const float4*>(g.A + (long long)m * g.sam + k);
       else v = *reinterpret_cast<const float4*>(g.A + (long long)k * g.sak + m);
@@ -82,6 +98,18 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const GemmArgs g) {
   auto load_b = [&](int k0) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n = n0 + b_r, k = k0 + b_k;
+    if (!g.vec) {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nn = B_KC ? n : n + q, kk = B_KC ? k + q : k;
+        if (nn < g.N && kk < kend) {
+          e[q] = g.B[(long long)kk * g.sbk + (long long)nn * g.sbn];
+          if constexpr (TR == 2) e[q] = fmaxf(fmaf(e[q], g.tr_sc[nn], g.tr_sh[nn]), 0.f);
+        }
+      }
+      return make_float4(e[0], e[1], e[2], e[3]);
+    }
     if (n < g.N && k < kend) {
       if constexpr (B_KC) v = *reinterpret_cast<const float4*>(g.B + (long long)n * g.sbn + k);
       else v = *reinterpret_cast<const float4*>(g.B + (long long)k * g.sbk + n);
@@ -183,9 +211,25 @@ struct ColArgs {
   int rows, H;
 };
 
-__device__ __forceinline__ void ldf4(const float* p, float (&v)[4]) {
-  const float4 t = *reinterpret_cast<const float4*>(p);
-  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+// four consecutive columns c0 .. c0+3 of a row of H: one float4 when H is a multiple of 4 (every quad whole and
+// aligned), element accesses with their own bound otherwise (columns past H read 0 / are not written)
+__device__ __forceinline__ void ldf4(const float* row, int c0, int H, float (&v)[4]) {
+  if ((H & 3) == 0) {
+    const float4 t = *reinterpret_cast<const float4*>(row + c0);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = c0 + q < H ? row[c0 + q] : 0.f;
+  }
+}
+__device__ __forceinline__ void stf4(float* row, int c0, int H, const float (&v)[4]) {
+  if ((H & 3) == 0) {
+    *reinterpret_cast<float4*>(row + c0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (c0 + q < H) row[c0 + q] = v[q];
+  }
 }
 
 __host__ __device__ inline int col_lanes(int H) {
@@ -203,14 +247,14 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
   const bool live = c0 < a.H;
   float sc[4] = {}, sh[4] = {}, mu[4] = {}, is[4] = {}, wo[4] = {}, ma[4] = {}, mb[4] = {};
   if (live) {
-    ldf4(a.consts + c0, sc);
-    ldf4(a.consts + a.H + c0, sh);
-    ldf4(a.consts + 2 * a.H + c0, mu);
-    ldf4(a.consts + 3 * a.H + c0, is);
-    if (a.w_o) ldf4(a.w_o + c0, wo);
+    ldf4(a.consts, c0, a.H, sc);
+    ldf4(a.consts + a.H, c0, a.H, sh);
+    ldf4(a.consts + 2 * a.H, c0, a.H, mu);
+    ldf4(a.consts + 3 * a.H, c0, a.H, is);
+    if (a.w_o) ldf4(a.w_o, c0, a.H, wo);
     if (MODE == CP_BAPPLY) {
-      ldf4(a.bmeans + c0, ma);
-      ldf4(a.bmeans + a.H + c0, mb);
+      ldf4(a.bmeans, c0, a.H, ma);
+      ldf4(a.bmeans + a.H, c0, a.H, mb);
     }
   }
   const float bias_o = (MODE == CP_OUT) ? a.b_o[0] : 0.f;
@@ -222,7 +266,7 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
     const int m = mrow + slot;
     const bool row_ok = m < a.rows;
     float y[4] = {0.f, 0.f, 0.f, 0.f}, act[4];
-    if (live && row_ok) ldf4(a.Y + (size_t)m * a.H + c0, y);
+    if (live && row_ok) ldf4(a.Y + (size_t)m * a.H, c0, a.H, y);
 #pragma unroll
     for (int v = 0; v < 4; ++v) act[v] = fmaxf(fmaf(y[v], sc[v], sh[v]), 0.f);
     if constexpr (MODE == CP_OUT) {
@@ -242,7 +286,7 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
       float go = 0.f;
       if (a.dA) {
         gsrc[0] = gsrc[1] = gsrc[2] = gsrc[3] = 0.f;
-        if (live && row_ok) ldf4(a.dA + (size_t)m * a.H + c0, gsrc);
+        if (live && row_ok) ldf4(a.dA + (size_t)m * a.H, c0, a.H, gsrc);
       } else {
         go = row_ok ? a.d_out[m] : 0.f;
 #pragma unroll
@@ -269,7 +313,7 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
           o[v] = sc[v] * (dyh[v] - ma[v] - yh[v] * mb[v]);   // BatchNorm backward, sc = gamma * rstd
           if (row_ok) s0[v] += (double)o[v];                 // d bias of the Linear (analytically 0)
         }
-        if (live && row_ok) *reinterpret_cast<float4*>(a.dY + (size_t)m * a.H + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (live && row_ok) stf4(a.dY + (size_t)m * a.H, c0, a.H, o);
       }
     }
   }
@@ -282,7 +326,8 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(const ColArgs a) {
       __syncthreads();
       if (live) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) red[slot * a.H + c0 + v] = src[qn][v];
+        for (int v = 0; v < 4; ++v)
+          if (c0 + v < a.H) red[slot * a.H + c0 + v] = src[qn][v];
       }
       __syncthreads();
       for (int c = tid; c < a.H; c += 256) {
@@ -383,8 +428,10 @@ constexpr int MLP_COL_GRID_MAX = 1024;
 constexpr int MLP_SPLIT_MAX = 64;
 
 bool mlp_train_shape_ok(int rows, int d_in, int hidden, int layers) {
+  // hidden: any width up to 512 (the reference class's default inter_num); widths that are not a multiple of 4
+  // stage their operands element by element.  d_in is the model's embedding width (16 / 32 / 64 / 128).
   return rows > 1 && layers >= 2 && layers <= 8 && d_in % 4 == 0 && d_in >= 4 && d_in <= 256 &&
-         hidden % 4 == 0 && hidden >= 4 && hidden <= 512;      // (512 = the reference class's default inter_num)
+         hidden >= 1 && hidden <= 512;
 }
 
 int col_grid(int rows, int H) {
@@ -481,6 +528,7 @@ extern "C" int gdn_mlp_train_fwd(const float* act, const float* const* params, f
     const float* const* p = params + 4 * l;
     if (!p[0] || !p[1] || !p[2] || !p[3]) return GDN_ERR_ARG;
     GemmArgs g = {};
+    g.vec = (hidden & 3) == 0;
     g.A = in; g.sam = K; g.sak = 1;
     g.B = p[0]; g.sbk = 1; g.sbn = K;          // B(k, n) = W[n][k]
     g.C = Y; g.M = rows; g.N = hidden; g.K = K; g.kslice = K;
@@ -529,6 +577,7 @@ extern "C" int gdn_mlp_eval_fwd(const float* act, const float* const* params, co
     const float* const* p = params + 4 * l;
     if (!p[0] || !p[1] || !p[2] || !p[3] || !running[2 * l] || !running[2 * l + 1]) return GDN_ERR_ARG;
     GemmArgs g = {};
+    g.vec = (hidden & 3) == 0;
     g.A = in; g.sam = K; g.sak = 1;
     g.B = p[0]; g.sbk = 1; g.sbn = K;
     g.C = Y; g.M = rows; g.N = hidden; g.K = K; g.kslice = (K + TK - 1) / TK * TK;
@@ -592,6 +641,7 @@ extern "C" int gdn_mlp_train_bwd(const float* d_out, const float* act, const flo
       kslice = (kslice + TK - 1) / TK * TK;
       const int used = (rows + kslice - 1) / kslice;
       GemmArgs g = {};
+      g.vec = (hidden & 3) == 0;
       g.A = dY; g.sam = 1; g.sak = hidden;        // A(m' = h, k' = row) = dY[row][h]
       g.M = hidden; g.N = K; g.K = rows; g.kslice = kslice;
       g.C = used > 1 ? split : gr[0];
@@ -614,6 +664,7 @@ extern "C" int gdn_mlp_train_bwd(const float* d_out, const float* act, const flo
     // dA_l[m][k] = sum_h dY[m][h] * W[h][k]
     {
       GemmArgs g = {};
+      g.vec = (hidden & 3) == 0;
       g.A = dY; g.sam = hidden; g.sak = 1;
       g.B = p[0]; g.sbk = K; g.sbn = 1;
       g.C = l == 0 ? d_act : dA; g.M = rows; g.N = K; g.K = hidden; g.kslice = hidden;

@@ -14,13 +14,13 @@ forward on CPU tensors raises.
                              range guard: inputs beyond the 16-bit operand range are detected on the device
                              and the launch is redone by the fp32 row-gather kernel — include/gdn_hip.h)
   eval, otherwise          : project -> attention/aggregate -> head kernels, then the OutLayer MLP as ONE
-                             matrix-core launch (gdn_mlp_fwd; hidden 260..512: gdn_mlp_eval_fwd, fp32 matrix-core
-                             GEMMs; beyond that or not a multiple of 4: torch's library GEMMs)
+                             matrix-core launch (gdn_mlp_fwd; hidden 257..512: gdn_mlp_eval_fwd, fp32 matrix-core
+                             GEMMs; beyond 512: torch's library GEMMs)
   train, out_layer_num == 1: project + attention/aggregate AND the BatchNorm/ReLU/embedding/dropout/Linear
                              head run as HIP kernels forward and backward (the autograd.Functions below)
   train, otherwise         : the same, with the head passes ending at the dropped-out activation and the
-                             OutLayer MLP on the fp32 matrix cores (gdn_mlp_train_fwd/bwd; hidden not a
-                             multiple of 4 or > 512: torch ops)
+                             OutLayer MLP on the fp32 matrix cores (gdn_mlp_train_fwd/bwd, any hidden width
+                             up to 512; beyond: torch ops)
                              (`loss.backward()` reaches every parameter exactly as in the reference)
   harness.NativeTrainStep is the same arithmetic without autograd (flat buffers, in-kernel dropout, gdn_adam_step).
 """
@@ -494,9 +494,9 @@ class GDN(nn.Module):
                 c.mlp = ops.mlp_plan(self.out_layer, emb.shape[1])
             if c.mlp is not None:                                           # GDN.py:183 on the matrix cores
                 return ops.mlp_fwd(h2, c.mlp).view(batch, node_num)
-            if ops.mlp_eval_wide_supported(self.out_layer, emb.shape[1]):   # hidden 260 .. 512: fp32 matrix-core GEMMs
+            if ops.mlp_eval_wide_supported(self.out_layer, emb.shape[1]):   # hidden 257 .. 512: fp32 matrix-core GEMMs
                 return ops.mlp_eval_wide(h2, self.out_layer).view(batch, node_num)
-            with torch.no_grad():       # hidden > 512 or not a multiple of 4: library GEMMs through torch
+            with torch.no_grad():       # hidden > 512: library GEMMs through torch
                 out = self.out_layer(h2.view(batch, node_num, -1))
             return out.view(-1, node_num)
 
@@ -520,7 +520,7 @@ class GDN(nn.Module):
                                         self.bn_outlayer_in.bias, mask, mask_scale, layer.bn, self.bn_outlayer_in,
                                         self.out_layer, batch, *mlp_params)
             return out.view(batch, node_num)
-        # MLP head outside gdn_mlp_train_fwd's shapes (hidden not a multiple of 4, or > 512): torch for the BN
+        # MLP head outside gdn_mlp_train_fwd's shapes (hidden > 512, or hidden layers of different widths): torch for the BN
         # statistics, dropout and the library GEMMs
         h = layer.relu(layer.bn(z))                                         # GDN.py:77-79
         h = h.view(batch, node_num, -1)                                     # GDN.py:171-172

@@ -335,8 +335,8 @@ def mlp_train_layers(out_layer):
 
 
 def mlp_train_supported(out_layer, d_in: int, rows: int) -> bool:
-    """True when gdn_mlp_train_fwd/bwd take this OutLayer: 2..8 layers, d_in (<= 256) and hidden (<= 512) multiples
-    of 4, every hidden layer of the same width."""
+    """True when gdn_mlp_train_fwd/bwd take this OutLayer: 2..8 layers, d_in (<= 256) a multiple of 4, hidden
+    1..512, every hidden layer of the same width."""
     parts = mlp_train_layers(out_layer)
     if parts is None:
         return False
@@ -348,7 +348,7 @@ def mlp_train_supported(out_layer, d_in: int, rows: int) -> bool:
 
 
 def mlp_eval_wide_supported(out_layer, d_in: int) -> bool:
-    """True when gdn_mlp_eval_fwd takes this OutLayer (eval mode, hidden up to 512, multiples of 4, running
+    """True when gdn_mlp_eval_fwd takes this OutLayer (eval mode, hidden up to 512, running
     statistics tracked): the path for widths beyond the one-launch chain (mlp_plan / mlp_fwd: hidden <= 256)."""
     parts = mlp_train_layers(out_layer)
     if parts is None:

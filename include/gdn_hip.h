@@ -247,8 +247,8 @@ int gdn_head_train_bwd_act(const float* d_act, const float* z, const float* emb,
  * of pointers live in HOST memory and hold device pointers.  `saved` (gdn_mlp_train_saved_bytes) carries the
  * pre-BatchNorm outputs and the batch constants from the forward to the backward; `workspace`
  * (gdn_mlp_train_workspace_bytes) is scratch.  grads[4*l .. 4*l+3] = gradients in the layout of params.
- * Supported: layers 2..8, d_in and hidden multiples of 4 up to 256 (else GDN_ERR_UNSUPPORTED; the byte
- * counts are 0 then).                                                                                     */
+ * Supported: layers 2..8, d_in a multiple of 4 up to 256, hidden 1..512 (widths that are not a multiple of 4
+ * stage their operands element by element); else GDN_ERR_UNSUPPORTED and byte counts of 0.                                                                                   */
 long long gdn_mlp_train_saved_bytes(int rows, int d_in, int hidden, int layers);
 long long gdn_mlp_train_workspace_bytes(int rows, int d_in, int hidden, int layers);
 int gdn_mlp_train_fwd(const float* act, const float* const* params, float* const* running,
@@ -265,7 +265,7 @@ int gdn_mlp_train_bwd(const float* d_out, const float* act, const float* const* 
  * take (hidden > 256; up to 512 = the reference class's default inter_num): one fp32 matrix-core GEMM per hidden
  * layer, the BatchNorm + ReLU folded into the next GEMM's operand staging, a column pass for the last Linear.
  * params / running as gdn_mlp_train_fwd (host arrays of device pointers; running must be non-null here).
- * hidden and d_in multiples of 4; workspace: gdn_mlp_eval_workspace_bytes (0 = unsupported shape).          */
+ * hidden 1..512, d_in a multiple of 4; workspace: gdn_mlp_eval_workspace_bytes (0 = unsupported shape).    */
 long long gdn_mlp_eval_workspace_bytes(int rows, int d_in, int hidden, int layers);
 int gdn_mlp_eval_fwd(const float* act, const float* const* params, const float* const* running,
                      const float* eps, const float* out_w, const float* out_b,

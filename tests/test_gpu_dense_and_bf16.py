@@ -289,7 +289,10 @@ def test_bf16_staged_kernels_refuse_shapes_outside_the_matrix_core_path(gpu_devi
                                  # beyond the one-launch chain (hidden > 256): gdn_mlp_eval_fwd, fp32 matrix-core GEMMs;
                                  # 512 = the default inter_num of the reference's OutLayer class (models/GDN.py:28)
                                  dict(n=127, w=15, k=30, d=64, hidden=512, layers=2, b=9),
-                                 dict(n=27, w=10, k=8, d=64, hidden=384, layers=3, b=21)],
+                                 dict(n=27, w=10, k=8, d=64, hidden=384, layers=3, b=21),
+                                 # widths that are not a multiple of 4 (element-wise operand staging)
+                                 dict(n=27, w=10, k=8, d=64, hidden=50, layers=3, b=21),
+                                 dict(n=27, w=10, k=8, d=32, hidden=301, layers=3, b=21)],
                          ids=lambda c: "n{n}_d{d}_h{hidden}_L{layers}".format(**c))
 def test_outlayer_mlp_on_the_matrix_cores(cfg, gpu_device):
     """out_layer_num > 1 in eval mode: gdn_mlp_fwd (one launch, activations in registers, BatchNorm folded into

@@ -435,7 +435,10 @@ def test_native_step_is_refused_for_shapes_outside_the_training_kernels(gpu_devi
 # ---------------------------------------------------------------- train-mode OutLayer MLP (out_layer_num > 1)
 @pytest.mark.parametrize("rows,d_in,hidden,layers", [(60, 32, 48, 2), (60, 16, 24, 3), (4064, 64, 256, 2),
                                                      (2033, 64, 512, 2), (517, 64, 384, 3), (130, 128, 260, 2),
-                                                     (3456, 64, 128, 3), (1000, 128, 64, 4), (131, 64, 256, 2)])
+                                                     (3456, 64, 128, 3), (1000, 128, 64, 4), (131, 64, 256, 2),
+                                                     # hidden widths that are not a multiple of 4
+                                                     (300, 64, 50, 3), (130, 32, 301, 2), (77, 16, 1, 2),
+                                                     (515, 64, 257, 3)])
 def test_mlp_train_kernels_match_fp64_autograd(rows, d_in, hidden, layers, gpu_device):
     """gdn_mlp_train_fwd / gdn_mlp_train_bwd (fp32 matrix cores, fp64 statistics) against the reference's
     OutLayer (models/GDN.py:27-56) run by torch autograd in float64: output, every parameter gradient, the
@@ -489,13 +492,14 @@ def test_mlp_train_kernels_match_fp64_autograd(rows, d_in, hidden, layers, gpu_d
 
 def test_mlp_head_training_uses_the_hip_mlp(gpu_device, monkeypatch):
     """out_layer_num = 2 under model.train(): forward + backward go through _MlpHeadTrainFn (HIP head passes
-    + HIP MLP); a hidden width outside the HIP set (not a multiple of 4) falls back to torch instead of failing."""
+    + HIP MLP); a hidden width that is not a multiple of 4 runs there too (element-wise operand staging), one beyond the
+    HIP set (> 512) falls back to torch instead of failing."""
     import gdn_amd
     from gdn_amd import ops
     calls = []
     orig = ops.mlp_train_fwd
     monkeypatch.setattr(ops, "mlp_train_fwd", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
-    for hidden, expect in ((256, 1), (250, 0)):
+    for hidden, expect in ((256, 1), (250, 1), (600, 0)):
         torch.manual_seed(0)
         model = gdn_amd.GDN([torch.zeros((2, 1), dtype=torch.long)], 27, dim=64, input_dim=15, out_layer_num=2,
                             out_layer_inter_dim=hidden, topk=10).to(gpu_device).train()
