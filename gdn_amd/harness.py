@@ -14,7 +14,9 @@
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import gc
 import os
 
 import torch
@@ -25,6 +27,24 @@ from . import ops
 
 
 # --------------------------------------------------------------------------- eval loop
+
+@contextlib.contextmanager
+def capture(graph, pool=None):
+    """`torch.cuda.graph(graph)` with the cyclic garbage collector out of the way.  torch 2.10 no longer collects
+    on entry, and a collection that fires INSIDE the captured region can finalise an older `CUDAGraph` or free a
+    cached block of a dead graph pool — HIP calls that are illegal while a stream is capturing; the error is
+    raised from a destructor and ends the process (seen once in the GPU suite: `Fatal Python error: Aborted` under
+    `Garbage-collecting`).  So: collect before, keep the collector disabled until the capture has ended."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, pool=pool):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
 def test(model, dataloader, device=None, as_tensors: bool = False):
     """Mirror of the reference test() (test.py:21-79).  Returns (avg_loss, [predictions, ground
     truth, labels]) with the three results as python lists, exactly like the reference; per-batch
@@ -401,7 +421,7 @@ class ShardedEvaluator:
             for fn, args in [(self._seg_forward, (c,)) for c in range(self.nchunks)] + [(self._seg_select, ()),
                                                                                          (self._seg_finish, ())]:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with capture(g):
                     out = fn(*args)
                 graphs.append(g)
             self._graphs, self._result = graphs, out
@@ -561,7 +581,7 @@ class SeriesEvaluator:
         fn()                                         # warm-up (occupancy queries, attributes)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with capture(g):
             fn()
         return g
 
@@ -692,12 +712,12 @@ class AutogradTrainStep:
         if self._split:
             for fn in (self._forward_backward, self._update):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with capture(g, pool=pool):
                     fn()
                 graphs.append(g)
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with capture(g, pool=pool):
                 self._forward_backward()
                 self._update()
             graphs.append(g)
@@ -1039,12 +1059,12 @@ class NativeTrainStep:
         if self._split:
             for fn in (self._forward_backward, self._adam):
                 g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
+                with capture(g_):
                     fn()
                 graphs.append(g_)
         else:
             g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
+            with capture(g_):
                 self._forward_backward()
                 self._adam()
             graphs.append(g_)

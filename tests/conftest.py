@@ -38,3 +38,14 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _collect_graph_garbage(request):
+    """GPU tests leave captured HIP graphs behind in reference cycles; a cyclic collection that happens to fire
+    inside a LATER test's stream capture would destroy them there, which HIP forbids (the process aborts).  Collect
+    at the end of every GPU test instead.  (The product's own captures are protected by harness.capture.)"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        gc.collect()
