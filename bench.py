@@ -515,9 +515,9 @@ def run():
         if _lib.load().gdn_train_supported(N_SENSORS, WINDOW, DIM, TOPK):
             line = train_step_line(device, n=x.shape[1], w=x.shape[2], batch=args.batch, dist=dist,
                                    split=world > 1 or args.rehearse_dist)
-        else:       # 512 sensors at d = 128: the backward's [n+1, d] fp32 tile (263 KB) exceeds the 160 KB of LDS
-            line = {"ms_per_step": None, "note": "gdn_train_supported() == 0 at this shape: the backward keeps the whole "
-                                                  "[n+1, d] fp32 tile in LDS (no column slicing yet)"}
+        else:       # e.g. > ~600 sensors: not even a 64-column slice of the backward's [n+1, d] fp32 tile fits LDS
+            line = {"ms_per_step": None, "note": "gdn_train_supported() == 0 at this shape (the backward's tile slice "
+                                                  "exceeds the 160 KB of LDS)"}
         if rank == 0:
             result["train_step"] = line
     if rank == 0 and world == 1:
