@@ -323,7 +323,7 @@ def run():
     ap.add_argument("--ticks", type=int, default=32768, help="windows per rank per step (SURVEY §8d)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="side streams the forward launches of a step rotate over (matters with --coalesce 1: one launch "
                          "per minibatch; a step that is ONE launch uses no side stream)")
     ap.add_argument("--sharded-graph", action="store_true",

@@ -28,6 +28,8 @@ SIGNATURES = {
     "gdn_head_train_fwd": [_p] * 10 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 9,
     "gdn_head_train_workspace_bytes": [_c_int, _c_int],
     "gdn_head_train_stats_bytes": [_c_int],
+    "gdn_exact_sum_workspace_bytes": [],
+    "gdn_exact_sum": [_p, _c_int, _p, _p, _p],
     "gdn_head_train_bwd": [_p] * 10 + [_c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 10,
     "gdn_head_train_fwd_rng": [_p] * 9 + [_c_float] + [_c_int] * 3 + [_c_float] * 4 + [_p] * 8 + [_c_int, _p],
     "gdn_head_train_bwd_rng": [_p] * 9 + [_c_float, _p] + [_c_int] * 3 + [_c_float] * 2 + [_p] * 9 + [_c_int, _p],

@@ -11,9 +11,17 @@
 // Everything is recomputed from z in each pass, so no [B*N, d] intermediate is ever stored; a pass
 // streams z (and the dropout mask) once and is HBM bound.  Forward = 3 passes (statistics of z,
 // statistics of h1, output), backward = 3 passes (BN2 reductions + Linear gradients, BN1 reductions +
-// embedding gradient, d_z).  Column reductions are carried in fp64 — per thread, across the
-// workgroup through LDS and across workgroups with fp64 atomics — so the result does not depend on
-// the accumulation order to fp32 precision.
+// embedding gradient, d_z).  Column reductions are carried in fp64 per thread and across the workgroup
+// (LDS, fixed order).
+//
+// [r3] The sums ACROSS workgroups are exact: a workgroup's fp64 column partial is split into the limbs of a
+// 260-bit fixed-point number (5 x 52 bits, lowest bit 2^-130: everything a product of two fp32 values can be) and
+// added limb by limb with 64-bit INTEGER atomics.  Integer addition is associative, so the totals — and with them
+// every statistic, gradient and parameter of a training step — do not depend on the order the workgroups finish
+// in: bitwise reproducible by construction (fp64 atomics, rounds 1-2, left 1e-16 relative noise in the sums, which
+// var = E[z^2] - E[z]^2 amplifies when a channel's mean dwarfs its spread).  A row of totals is converted back to
+// fp64 by the first pass that consumes it and kept for the later ones.  Price: two integer atomics per value
+// instead of one fp64 atomic and ~1.5 us of prologue in four passes: 0.169 -> 0.181 ms per 512-window step.
 //
 // Thread layout: a row (one sensor of one window) is covered by LPR = d/4 consecutive lanes holding
 // four columns each.  A workgroup takes SLOTS = 256/LPR consecutive sensors and a part of the batch;
@@ -29,7 +37,10 @@ struct HG {
   static constexpr int SLOTS = 256 / LPR;
 };
 
-#define GDN_HEAD_REPL 4       // replicas of every column accumulator: same-address fp64 atomics serialise
+#define GDN_HEAD_REPL 4       // replicas of every column accumulator: same-address atomics serialise
+#define GDN_FX_LIMBS 5        // fixed-point accumulator: limbs of 52 bits, limb k = bits 52k .. 52k+51 above 2^-130
+#define GDN_FX_WORDS 6        // + one flag word (NaN / inf / beyond 2^130 seen: the total reads as NaN)
+#define GDN_FX_LSB 130
 #define GDN_HEAD_EMB_PARTS 64  // batch parts of the embedding-gradient pass, one [n,d] partial each
 
 struct RunningStats {   // BatchNorm buffers updated by the forward (any pointer may be null)
@@ -58,8 +69,10 @@ struct HeadArgs {
   const long long* rng;  // third alternative: {seed, step} in device memory -> the mask is DRAWN here (no tensor)
   unsigned rng_threshold;   // element dropped when its 32-bit hash < threshold (= p * 2^32)
   RunningStats run;
-  const double* fstats;  // [REPL][4][d]: sum z, sum z^2, sum h1, sum h1^2
-  double* acc;           // forward passes: fstats (writable); backward: [REPL][6][d] workspace
+  // an accumulator block of R rows = [R][d] fp64 totals (filled in as passes convert them), then the
+  // [REPL][R][FX_WORDS][d] 64-bit accumulator words
+  const double* fstats;  // R = 4: sum z, sum z^2, sum h1, sum h1^2
+  double* acc;           // forward passes: fstats (writable); backward: R = 6 (head of the workspace)
   float* demb_part;      // backward: [EMB_PARTS][n][d] per-part sums of d_emb
   float *out, *d_z;
   // forward, fused loss (train.py:20-23 F.mse_loss + the first step of loss.backward()): when y is given the
@@ -80,12 +93,78 @@ struct BnCols {
   float mu[4], is[4], sc[4], be[4];
 };
 
-// sum of one accumulator row over its replicas; `stride` = doubles between replicas
-__device__ __forceinline__ double repl_sum(const double* p, int stride) {
+// ---- exact accumulation across workgroups (see the header) --------------------------------------------------
+// An accumulator is GDN_FX_WORDS 64-bit words `stride` words apart (one per limb, then the flag).  Every limb
+// receives at most one addend below 2^52 per call: 2048 calls between two resets cannot overflow its 63 bits.
+__device__ __forceinline__ void fx_atomic_add(unsigned long long* p, int stride, double x) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const int ex = (int)((bits >> 52) & 0x7ffull);
+  if (ex == 0) return;                                        // 0 (or below 2^-1022)
+  unsigned long long* flag = p + (size_t)GDN_FX_LIMBS * stride;
+  if (ex == 0x7ff) { atomicOr(flag, 1ull); return; }          // NaN / inf
+  unsigned long long mant = (bits & ((1ull << 52) - 1ull)) | (1ull << 52);
+  int pos = ex - 1075 + GDN_FX_LSB;                           // position of the mantissa's lowest bit
+  if (pos < 0) {                                              // bits below 2^-130 are dropped (towards zero)
+    if (pos <= -53) return;
+    mant >>= -pos;
+    pos = 0;
+  }
+  const int k = pos / 52, o = pos - 52 * k;
+  const unsigned __int128 v = (unsigned __int128)mant << o;   // < 2^104: two limbs
+  long long l0 = (long long)(unsigned long long)(v & (((unsigned __int128)1 << 52) - 1));
+  long long l1 = (long long)(unsigned long long)(v >> 52);
+  if (k >= GDN_FX_LIMBS || (l1 != 0 && k + 1 >= GDN_FX_LIMBS)) { atomicOr(flag, 1ull); return; }
+  if (bits >> 63) { l0 = -l0; l1 = -l1; }
+  if (l0 != 0) atomicAdd(p + (size_t)k * stride, (unsigned long long)l0);
+  if (l1 != 0) atomicAdd(p + (size_t)(k + 1) * stride, (unsigned long long)l1);
+}
+
+// value of an accumulator summed over its replicas (`repl_stride` words apart): limb sums are exact integers,
+// carries are propagated, the magnitude is converted limb by limb from the top (no cancellation)
+__device__ __forceinline__ double fx_total(const unsigned long long* p, int stride, size_t repl_stride) {
+  long long l[GDN_FX_LIMBS];
+  unsigned long long flag = 0ull;
+  unsigned long long w[GDN_HEAD_REPL][GDN_FX_WORDS];
+#pragma unroll
+  for (int r = 0; r < GDN_HEAD_REPL; ++r)
+#pragma unroll
+    for (int k = 0; k < GDN_FX_WORDS; ++k) w[r][k] = p[r * repl_stride + (size_t)k * stride];   // all loads in flight
+#pragma unroll
+  for (int k = 0; k < GDN_FX_LIMBS; ++k) l[k] = 0;
+#pragma unroll
+  for (int r = 0; r < GDN_HEAD_REPL; ++r) {
+#pragma unroll
+    for (int k = 0; k < GDN_FX_LIMBS; ++k) l[k] += (long long)w[r][k];
+    flag |= w[r][GDN_FX_LIMBS];
+  }
+  if (flag) return __longlong_as_double(0x7ff8000000000000ll);
+  auto carry = [&]() {
+#pragma unroll
+    for (int k = 0; k + 1 < GDN_FX_LIMBS; ++k) {
+      const long long c = l[k] >> 52;            // floor: the limb lands in [0, 2^52)
+      l[k] -= c << 52;
+      l[k + 1] += c;
+    }
+  };
+  carry();
+  const bool neg = l[GDN_FX_LIMBS - 1] < 0;
+  if (neg) {
+#pragma unroll
+    for (int k = 0; k < GDN_FX_LIMBS; ++k) l[k] = -l[k];
+    carry();
+  }
   double s = 0.0;
-#pragma unroll 4
-  for (int r = 0; r < GDN_HEAD_REPL; ++r) s += p[(size_t)r * stride];
-  return s;
+#pragma unroll
+  for (int k = GDN_FX_LIMBS - 1; k >= 0; --k)     // exact scaling: the factor is the double 2^(52k - 130)
+    s += (double)l[k] * __longlong_as_double((long long)(1023 + 52 * k - GDN_FX_LSB) << 52);
+  return neg ? -s : s;
+}
+// word offset of limb 0 of accumulator (replica, row, column) in a block of `rows` rows
+__host__ __device__ __forceinline__ size_t fx_at(int repl, int rows, int row, int d, int col) {
+  return (size_t)rows * d + (((size_t)repl * rows + row) * GDN_FX_WORDS) * d + col;
+}
+__host__ __device__ __forceinline__ size_t fx_block_words(int rows, int d) {
+  return (size_t)rows * d + (size_t)GDN_HEAD_REPL * rows * GDN_FX_WORDS * d;
 }
 
 __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
@@ -96,8 +175,8 @@ __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
 // sum the per-thread column partials over the workgroup's SLOTS lane groups, then one fp64 atomic per
 // column per workgroup
 template <int D>
-__device__ __forceinline__ void col_reduce(const double (&v)[4], double* red, double* gdst, int tid, int slot,
-                                           int c0) {
+__device__ __forceinline__ void col_reduce(const double (&v)[4], double* red, unsigned long long* gdst, int tid,
+                                           int slot, int c0) {
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) red[slot * D + c0 + q] = v[q];
@@ -105,7 +184,7 @@ __device__ __forceinline__ void col_reduce(const double (&v)[4], double* red, do
   if (tid < D) {
     double s = 0.0;
     for (int q = 0; q < HG<D>::SLOTS; ++q) s += red[q * D + tid];
-    atomicAdd(gdst + tid, s);
+    fx_atomic_add(gdst + tid, D, s);
   }
 }
 
@@ -170,8 +249,37 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   __shared__ double tot[8 * D];
   constexpr int NF = MODE >= H_OUT ? 4 : (MODE >= H_STAT2 ? 2 : 0);
   constexpr int NB = MODE == H_DZ ? 4 : (MODE == H_BWD1 ? 2 : 0);
-  for (int t = tid; t < NF * D; t += 256) tot[t] = repl_sum(a.fstats + t, 4 * D);
-  for (int t = tid; t < NB * D; t += 256) tot[4 * D + t] = repl_sum(a.acc + t, 6 * D);
+  const unsigned long long* fwords = reinterpret_cast<const unsigned long long*>(a.fstats);
+  unsigned long long* awords = reinterpret_cast<unsigned long long*>(a.acc);
+  // A row of totals is converted from its limbs by the FIRST pass that consumes it (every workgroup of that pass
+  // does the same exact integer arithmetic); workgroup 0 leaves the fp64 value in the block's totals, where the
+  // later passes read it: 8 row conversions per step instead of 24 (each costs a pass ~1.5 us of prologue).
+  //   forward rows 0,1: fresh in H_STAT2; rows 2,3: fresh in H_OUT.  backward rows 0,1: fresh in H_BWD1; rows
+  //   2,3: fresh in H_DZ; rows 4,5 (d_lin_w, d_lin_b) are converted by the finish kernel.
+  for (int t = tid; t < NF * D; t += 256) {
+    const int row = t / D;
+    const bool fresh = (MODE == H_STAT2) || (MODE == H_OUT && row >= 2);
+    double v;
+    if (fresh) {
+      v = fx_total(fwords + fx_at(0, 4, row, D, t % D), D, (size_t)4 * GDN_FX_WORDS * D);
+      if (blockIdx.x == 0) const_cast<double*>(a.fstats)[t] = v;
+    } else {
+      v = a.fstats[t];
+    }
+    tot[t] = v;
+  }
+  for (int t = tid; t < NB * D; t += 256) {
+    const int row = t / D;
+    const bool fresh = (MODE == H_BWD1) || (MODE == H_DZ && row >= 2);
+    double v;
+    if (fresh) {
+      v = fx_total(awords + fx_at(0, 6, row, D, t % D), D, (size_t)6 * GDN_FX_WORDS * D);
+      if (blockIdx.x == 0) a.acc[t] = v;
+    } else {
+      v = a.acc[t];
+    }
+    tot[4 * D + t] = v;
+  }
   if constexpr (NF > 0) __syncthreads();
 
   if constexpr (MODE == H_OUT) {
@@ -393,28 +501,26 @@ __global__ __launch_bounds__(256) void gdn_head_train_kernel(const HeadArgs a) {
   }
   const int repl = blockIdx.x % GDN_HEAD_REPL;
   if constexpr (MODE == H_STAT1 || MODE == H_STAT2) {
-    double* dst = a.acc + (size_t)repl * 4 * D + (MODE == H_STAT1 ? 0 : 2 * D);
-    col_reduce<D>(acc0, red, dst, tid, slot, c0);
-    col_reduce<D>(acc1, red, dst + D, tid, slot, c0);
+    const int r0 = MODE == H_STAT1 ? 0 : 2;
+    col_reduce<D>(acc0, red, awords + fx_at(repl, 4, r0, D, 0), tid, slot, c0);
+    col_reduce<D>(acc1, red, awords + fx_at(repl, 4, r0 + 1, D, 0), tid, slot, c0);
   }
   if constexpr (MODE == H_BWD2) {
-    double* dst = a.acc + (size_t)repl * 6 * D;
-    col_reduce<D>(acc0, red, dst, tid, slot, c0);
-    col_reduce<D>(acc1, red, dst + D, tid, slot, c0);
-    col_reduce<D>(acc2, red, dst + 4 * D, tid, slot, c0);
+    col_reduce<D>(acc0, red, awords + fx_at(repl, 6, 0, D, 0), tid, slot, c0);
+    col_reduce<D>(acc1, red, awords + fx_at(repl, 6, 1, D, 0), tid, slot, c0);
+    col_reduce<D>(acc2, red, awords + fx_at(repl, 6, 4, D, 0), tid, slot, c0);
     __syncthreads();
     red[tid] = acc_s;
     __syncthreads();
     if (tid == 0) {
       double s = 0.0;
       for (int q = 0; q < 256; ++q) s += red[q];
-      atomicAdd(dst + 5 * D, s);
+      fx_atomic_add(awords + fx_at(repl, 6, 5, D, 0), D, s);
     }
   }
   if constexpr (MODE == H_BWD1) {
-    double* dst = a.acc + (size_t)repl * 6 * D;
-    col_reduce<D>(acc0, red, dst + 2 * D, tid, slot, c0);
-    col_reduce<D>(acc1, red, dst + 3 * D, tid, slot, c0);
+    col_reduce<D>(acc0, red, awords + fx_at(repl, 6, 2, D, 0), tid, slot, c0);
+    col_reduce<D>(acc1, red, awords + fx_at(repl, 6, 3, D, 0), tid, slot, c0);
     if (live)   // every (part, sensor, column) has exactly one owner: plain store, summed by the finish kernel
       *reinterpret_cast<float4*>(a.demb_part + ((size_t)part * a.n + n) * D + c0) =
           make_float4((float)acc2[0], (float)acc2[1], (float)acc2[2], (float)acc2[3]);
@@ -426,22 +532,28 @@ __device__ __forceinline__ void head_finish_body(double* __restrict__ ws, const 
                                                  float* d_bn2_b, float* d_lin_w, float* d_lin_b, float* d_emb,
                                                  double* zero_stats, int block) {
   const int t = block * (int)blockDim.x + (int)threadIdx.x;
-  if (t < d && zero_stats) {
-    // last reader of both accumulator blocks (every pass of this step is complete): leave them zeroed for the
-    // next step, which then needs no memset launches.  Only the thread that reads a column clears it.
-    for (int r = 0; r < GDN_HEAD_REPL; ++r)
-      for (int q = 0; q < 4; ++q) zero_stats[((size_t)r * 4 + q) * d + t] = 0.0;
-  }
-  if (t < d) {
-    d_bn2_b[t] = (float)repl_sum(ws + t, 6 * d);
-    d_bn2_w[t] = (float)repl_sum(ws + d + t, 6 * d);
-    d_bn1_b[t] = (float)repl_sum(ws + 2 * d + t, 6 * d);
-    d_bn1_w[t] = (float)repl_sum(ws + 3 * d + t, 6 * d);
-    if (d_lin_w) d_lin_w[t] = (float)repl_sum(ws + 4 * d + t, 6 * d);
-    if (t == 0 && d_lin_b) d_lin_b[0] = (float)repl_sum(ws + 5 * d, 6 * d);
-    if (zero_stats)
-      for (int r = 0; r < GDN_HEAD_REPL; ++r)
-        for (int q = 0; q < 6; ++q) ws[((size_t)r * 6 + q) * d + t] = 0.0;
+  if (block == 0) {
+    // the six gradient rows of the head, then — every pass of this step is complete, this is the last reader —
+    // both accumulator blocks are left zeroed for the next step, which then needs no memset launches
+    __shared__ float fin[6 * 128];
+    unsigned long long* wsw = reinterpret_cast<unsigned long long*>(ws);
+    for (int i = (int)threadIdx.x; i < 6 * d; i += (int)blockDim.x)     // rows 0-3: converted by H_BWD1 / H_DZ
+      fin[i] = i < 4 * d ? (float)ws[i]
+                         : (float)fx_total(wsw + fx_at(0, 6, i / d, d, i % d), d, (size_t)6 * GDN_FX_WORDS * d);
+    __syncthreads();
+    if (zero_stats) {
+      unsigned long long* zs = reinterpret_cast<unsigned long long*>(zero_stats);
+      for (int i = (int)threadIdx.x; i < (int)fx_block_words(4, d); i += (int)blockDim.x) zs[i] = 0ull;
+      for (int i = (int)threadIdx.x; i < (int)fx_block_words(6, d); i += (int)blockDim.x) wsw[i] = 0ull;
+    }
+    for (int c = (int)threadIdx.x; c < d; c += (int)blockDim.x) {
+      d_bn2_b[c] = fin[c];
+      d_bn2_w[c] = fin[d + c];
+      d_bn1_b[c] = fin[2 * d + c];
+      d_bn1_w[c] = fin[3 * d + c];
+      if (d_lin_w) d_lin_w[c] = fin[4 * d + c];
+      if (c == 0 && d_lin_b) d_lin_b[0] = fin[5 * d];
+    }
   }
   if (t < n * d) {
     double s = 0.0;
@@ -541,6 +653,16 @@ __global__ __launch_bounds__(256) void gdn_mse_kernel(const float* __restrict__ 
   }
 }
 
+// gdn_exact_sum: the accumulator above on its own (tests pin it against an exactly rounded CPU sum)
+__global__ void gdn_exact_sum_kernel(const double* __restrict__ x, int count, unsigned long long* __restrict__ ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) fx_atomic_add(ws + (size_t)(i % GDN_HEAD_REPL) * GDN_FX_WORDS, 1, x[i]);
+}
+__global__ void gdn_exact_sum_finish_kernel(unsigned long long* __restrict__ ws, double* __restrict__ out) {
+  out[0] = fx_total(ws, 1, GDN_FX_WORDS);
+  for (int i = 0; i < GDN_HEAD_REPL * GDN_FX_WORDS; ++i) ws[i] = 0ull;
+}
+
 #define GDN_MSE_MAX_GRID 256
 
 bool head_shape_ok(int batch, int n, int d) {
@@ -548,6 +670,18 @@ bool head_shape_ok(int batch, int n, int d) {
 }
 
 }  // namespace
+
+extern "C" long long gdn_exact_sum_workspace_bytes(void) { return (long long)GDN_HEAD_REPL * GDN_FX_WORDS * 8; }
+
+extern "C" int gdn_exact_sum(const double* x, int count, void* workspace, double* out, void* stream) {
+  if (!x || !workspace || !out || count <= 0) return GDN_ERR_ARG;
+  if (count > 2048) return GDN_ERR_UNSUPPORTED;     // addends per limb between two resets
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gdn_exact_sum_kernel, dim3((count + 63) / 64), dim3(64), 0, st, x, count,
+                     static_cast<unsigned long long*>(workspace));
+  hipLaunchKernelGGL(gdn_exact_sum_finish_kernel, dim3(1), dim3(1), 0, st, static_cast<unsigned long long*>(workspace), out);
+  return gdn_launch_status();
+}
 
 extern "C" long long gdn_mse_workspace_bytes(void) { return (GDN_MSE_MAX_GRID + 1) * (long long)sizeof(double); }
 
@@ -562,12 +696,12 @@ extern "C" int gdn_mse_loss_grad(const float* out, const float* y, long long cou
 }
 
 extern "C" long long gdn_head_train_stats_bytes(int d) {
-  return d <= 0 ? 0 : (long long)GDN_HEAD_REPL * 4 * d * (long long)sizeof(double);
+  return d <= 0 ? 0 : (long long)fx_block_words(4, d) * (long long)sizeof(double);
 }
 
 extern "C" long long gdn_head_train_workspace_bytes(int n, int d) {
   if (n <= 0 || d <= 0) return 0;
-  return (long long)GDN_HEAD_REPL * 6 * d * (long long)sizeof(double) +
+  return (long long)fx_block_words(6, d) * (long long)sizeof(double) +
          (long long)GDN_HEAD_EMB_PARTS * n * d * (long long)sizeof(float);
 }
 
@@ -602,7 +736,7 @@ static int head_train_fwd_impl(const float* z, const float* emb, const float* bn
   a.y = y; a.mse_d_out = d_out; a.mse_ws = mse_ws; a.loss = loss;
   a.eps1 = eps1; a.eps2 = eps2;
   a.run = {running_mean1, running_var1, running_mean2, running_var2, batches1, batches2, momentum1, momentum2};
-  if (!zeroed && hipMemsetAsync(stats, 0, (size_t)GDN_HEAD_REPL * 4 * d * sizeof(double), st) != hipSuccess)
+  if (!zeroed && hipMemsetAsync(stats, 0, fx_block_words(4, d) * sizeof(double), st) != hipSuccess)
     return GDN_ERR_LAUNCH;
 #define GDN_HEAD_F(DD)                 \
   case DD:                             \
@@ -671,7 +805,7 @@ static int head_train_bwd_impl(const float* d_out, const float* z, const float* 
   }
   a.d_out = d_out; a.d_act = d_act; a.fstats = stats; a.acc = workspace; a.d_z = d_z; a.batch = batch; a.n = n;
   a.eps1 = eps1; a.eps2 = eps2;
-  const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
+  const size_t sums_bytes = fx_block_words(6, d) * sizeof(double);
   a.demb_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sums_bytes);
   if (!zeroed && hipMemsetAsync(workspace, 0, sums_bytes, st) != hipSuccess) return GDN_ERR_LAUNCH;
 #define GDN_HEAD_B(DD)                \
@@ -786,7 +920,7 @@ extern "C" int gdn_train_finish(double* head_workspace, double* stats, int head_
     return GDN_ERR_ARG;
   if (d != 16 && d != 32 && d != 64 && d != 128) return GDN_ERR_UNSUPPORTED;
   TailArgs t = {};
-  const size_t sums_bytes = (size_t)GDN_HEAD_REPL * 6 * d * sizeof(double);
+  const size_t sums_bytes = fx_block_words(6, d) * sizeof(double);
   const int chunks = (n + 256 / (d / 4) - 1) / (256 / (d / 4));
   const int total = n * d > d ? n * d : d;
   t.head_ws = head_workspace;

@@ -470,7 +470,7 @@ class SeriesEvaluator:
     are captured once in a HIP graph and replayed."""
 
     def __init__(self, model, x_all: torch.Tensor | None, y_all: torch.Tensor, batch: int, use_graph: bool = True,
-                 want_scores: bool = False, streams: int = 2, coalesce: int = 1,
+                 want_scores: bool = False, streams: int = 3, coalesce: int = 1,
                  series: torch.Tensor | None = None):
         """`batch` = the logical minibatch of the reference's loader; `coalesce` consecutive batches
         (contiguous in the resident series) go out as ONE launch — eval results do not depend on the
@@ -503,8 +503,10 @@ class SeriesEvaluator:
         # keys kernel 14 us (step 0.379 vs 0.352 ms).
         self.fuse_keys = os.environ.get("GDN_FUSE_KEYS", "0") == "1"
         # independent batches are launched round-robin on side streams (fork/join around the
-        # forward), so consecutive launches overlap each other's ramp-up and tail (two streams measured
-        # best at 4096-window launches: 0.634 ms/step vs 0.697 with one and 0.676 with four)
+        # forward), so consecutive launches overlap each other's ramp-up and tail.  Round 1, 4096-window launches:
+        # two streams 0.634 ms/step vs 0.697 with one and 0.676 with four.  Round 3, 512-window launches of two
+        # windows per workgroup (gdn_forward_dense.hip, fused_op): 72.2 M windows/s on two streams, 74.4 M on
+        # three, 69.9 M on four — three is the default
         n_launch = (self.t + self.batch - 1) // self.batch
         self.side = [torch.cuda.Stream(device=dev) for _ in range(min(streams, n_launch))] if streams > 1 else []
 

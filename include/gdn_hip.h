@@ -149,11 +149,18 @@ int gdn_mlp_fwd(const float* h2, const void* plan, int rows, int d_in, int hidde
  * as the caller's mask: either mask[BN,d] fp32 multipliers (0 or 1/(1-p)) or keep[BN,d] bytes
  * (1 kept / 0 dropped, multiplier = keep * keep_scale: a quarter of the traffic); both NULL =
  * no dropout; OutLayer Linear(d->1).
- *   stats (out)  gdn_head_train_stats_bytes(d) bytes: replicated fp64 column sums of z, z^2,
- *                h1, h1^2 — opaque, kept for the backward.
+ *   stats (out)  gdn_head_train_stats_bytes(d) bytes: the column sums of z, z^2, h1, h1^2 — opaque,
+ *                kept for the backward.  Sums across workgroups are EXACT (260-bit fixed point, 64-bit
+ *                integer atomics, see gdn_exact_sum): statistics and gradients do not depend on the
+ *                order the workgroups finish in.
  *   running_* / batches*     may be NULL (track_running_stats off).
  * Three streaming passes over z; nothing [BN,d]-sized is stored.  batch*n >= 2.             */
 long long gdn_head_train_stats_bytes(int d);
+/* The accumulator of the training statistics on its own: out[0] = the sum of x[0..count) (device fp64, count <=
+ * 2048), exact up to the final conversion to fp64 (values are held to 2^-130, NaN / inf / |x| >= 2^130 give NaN).
+ * workspace: gdn_exact_sum_workspace_bytes() bytes, zero on entry, left zero.  Exported for tests.          */
+long long gdn_exact_sum_workspace_bytes(void);
+int gdn_exact_sum(const double* x, int count, void* workspace, double* out, void* stream);
 int gdn_head_train_fwd(const float* z, const float* emb, const float* bn1_w, const float* bn1_b,
                        const float* bn2_w, const float* bn2_b, const float* lin_w,
                        const float* lin_b, const float* mask, const uint8_t* keep,

@@ -581,3 +581,48 @@ def test_graph_and_terms_single_launch_equals_the_two_entry_points(gpu_device):
         assert torch.equal(topk, graph.topk) and torch.equal(deg, graph.deg)
         assert torch.equal(nbr.view(torch.int16), graph.nbr.view(torch.int16))
         assert torch.equal(terms2, terms)
+
+
+def test_training_statistics_accumulator_is_exact(gpu_device):
+    """The cross-workgroup sums of the training head (BatchNorm statistics, BatchNorm / Linear gradients) go through a
+    260-bit fixed-point accumulator fed by 64-bit integer atomics (gdn_head_train.hip): the total does not depend on
+    the order of the addends.  gdn_exact_sum exposes it; against math.fsum (the exactly rounded sum) on addends that
+    defeat floating-point summation — cancellation over 60 orders of magnitude, every sign pattern, values at both
+    ends of the range — and bit for bit under a permutation of the addends."""
+    import math
+    from gdn_amd import _lib
+    lib = _lib.load()
+    ws = torch.zeros((lib.gdn_exact_sum_workspace_bytes() // 8,), dtype=torch.int64, device=gpu_device)
+    out = torch.zeros((1,), dtype=torch.float64, device=gpu_device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def hip_sum(values):
+        x = torch.tensor(values, dtype=torch.float64, device=gpu_device)
+        _lib.call("gdn_exact_sum", x.data_ptr(), x.numel(), ws.data_ptr(), out.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert int(ws.abs().sum()) == 0                      # left zeroed for the next use
+        return float(out[0])
+
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "cancellation": [1e30, 1.0, -1e30, 3.0e-20, 2.5, -3.0e-20],
+        "tiny": [2.0 ** -120, -(2.0 ** -121), 2.0 ** -125],
+        "huge": [2.0 ** 120, 2.0 ** 100, -(2.0 ** 119)],
+        "one": [0.1],
+        "zeros": [0.0, -0.0, 0.0],
+    }
+    mags = torch.randint(-80, 80, (2000,), generator=g).double()
+    rnd = ((torch.rand(2000, generator=g, dtype=torch.float64) - 0.5) * 2.0 ** mags).tolist()
+    cases["random_2000"] = rnd
+    cases["random_with_opposites"] = rnd[:1000] + [-v for v in rnd[:999]]
+    sq = (torch.randn(2048, generator=g).float().double() * 3.0e7) ** 2          # squares of raw-unit fp32 values
+    cases["squares"] = sq.tolist()
+    for name, vals in cases.items():
+        want = math.fsum(vals)
+        got = hip_sum(vals)
+        assert abs(got - want) <= 4 * abs(want) * 2.0 ** -53, (name, got, want)
+        perm = torch.randperm(len(vals), generator=g).tolist()
+        assert hip_sum([vals[i] for i in perm]) == got, name         # bit for bit
+    assert math.isnan(hip_sum([1.0, float("inf")])) and math.isnan(hip_sum([float("nan")]))
+    assert math.isnan(hip_sum([2.0 ** 131]))                         # beyond the accumulator's range: flagged, not wrapped
+    assert lib.gdn_exact_sum(0, 4096, 0, 0, 0) != 0                  # argument / size checks
