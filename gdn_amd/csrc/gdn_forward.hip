@@ -793,6 +793,8 @@ __device__ __forceinline__ void window_loop_mfma_chunked(const Plan& pl, const A
       const int k = 2 * kk + h;
       wb[cb][kk] = k < pl.w ? a.lin_w[(size_t)(GDN_COL0(D) + cb * 32 + l32) * pl.w + k] : 0.f;
     }
+  // (Measured, round 3, 16-wave form: reloading these 32 values per window instead of keeping them live through the
+  // gather loop — 128 registers a lane there — made it slower, 2.58 vs 3.81 M windows/s: more spills, not fewer.)
   const int cnt = pl.n * pl.w;
   const float inv_w = 1.0f / (float)pl.w;
   XFlat<XU> xcur, xnext;
@@ -866,7 +868,7 @@ __device__ __forceinline__ void stage_x(const Plan& pl, const Args& a, const flo
 // pay the registers of the hungriest one): 0 VALU w<=8, 1 VALU w-chunks of 16,
 // 2 MFMA w<=16 (<=8 x values per thread), 3 MFMA w<=16 (<=16 per thread), 4 MFMA w<=32.
 template <int D, int MODE, int NT, int PROJ, int LST>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ? 3 : 2), (NT == 256 ? 3 : 2)))) void gdn_window_kernel(const Plan pl, const Args a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ? 3 : (NT == 1024 ? 4 : 2)), (NT == 256 ? 3 : (NT == 1024 ? 4 : 2))))) void gdn_window_kernel(const Plan pl, const Args a) {
   using G = Geo<D>;
   constexpr int WCH = PROJ == 0 ? 8 : 16;
   extern __shared__ float4 smem_f4[];
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((NT == 256 ?
   } else {
     if constexpr (PROJ == 5) {
       static_assert(D >= 32, "MFMA projection needs d >= 32");
-      window_loop_mfma_chunked<D, MODE, 32, 32, LST>(pl, a, smem);
+      window_loop_mfma_chunked<D, MODE, 32, (NT == 1024 ? 16 : 32), LST>(pl, a, smem);
       if constexpr (MODE == MODE_FUSED) gate_release(a);
       return;
     } else if constexpr (PROJ >= 2) {
@@ -1137,6 +1139,14 @@ int make_plan(int mode, int batch, int n, int w, int d, int k, Plan* pl, int* th
       if (rows >= 32) {
         pl->mfma = 2; pl->wpm = 32; pl->xp = 33;
         pl->xrows = rows < ((n + 31) & ~31) ? rows : ((n + 31) & ~31);
+        // 16 waves per workgroup (4 per SIMD at 128 registers) when the window's x values fit 16 per thread: the
+        // one workgroup a CU holds at this tile size is latency bound with 8.  configs[4], 32768 windows: 3.51 ->
+        // 3.81 M windows/s (bf16-stored windows 3.14 -> 3.63 M).  Only the fused forward of launches that give a
+        // workgroup several windows: 512-window launches were 7 % slower with 16 waves, and the staged projection
+        // of a training step (157 spilled registers at 128) 5 %.  GDN_BIG_THREADS=512 keeps 8 waves (A/B runs).
+        if (mode == MODE_FUSED && n * w <= 16 * 1024 && batch >= 4 * gdn_cu_count() &&
+            GDN_ENV_INT_ONCE("GDN_BIG_THREADS", 1024) == 1024)
+          *threads = 1024;
       }
     }
   }
@@ -1207,11 +1217,16 @@ int select_maxr(const Plan& pl, const Args& a, hipStream_t st) {
 
 template <int D, int MODE, int NT>
 int select_proj(const Plan& pl, const Args& a, int threads, hipStream_t st) {
-  if constexpr (MODE == MODE_ATTN) {
+  if constexpr (NT == 1024) {      // only the chunked matrix-core projection runs 16-wave workgroups
+    if constexpr (MODE != MODE_ATTN && D >= 32) {
+      if (pl.mfma == 2) return select_maxr<D, MODE, NT, 5>(pl, a, st);
+    }
+    return GDN_ERR_UNSUPPORTED;
+  } else if constexpr (MODE == MODE_ATTN) {
     return select_maxr<D, MODE, NT, 1>(pl, a, st);
   } else {
     if constexpr (D >= 32) {
-      if (pl.mfma == 2) {      // chunked: x in registers, the LDS x tile one row chunk at a time (512 threads)
+      if (pl.mfma == 2) {      // chunked: x in registers, the LDS x tile one row chunk at a time (512 / 1024 threads)
         if constexpr (NT == 512) return select_maxr<D, MODE, NT, 5>(pl, a, st);
         else return GDN_ERR_UNSUPPORTED;
       }
@@ -1231,6 +1246,7 @@ int dispatch_window(const Plan& pl, const Args& a, int threads, hipStream_t stre
 #define GDN_CASE(DD)                                                              \
   case DD:                                                                        \
     if (threads == 256) return select_proj<DD, MODE, 256>(pl, a, threads, stream); \
+    if (threads == 1024) return select_proj<DD, MODE, 1024>(pl, a, threads, stream); \
     return select_proj<DD, MODE, 512>(pl, a, threads, stream);
   switch (pl.d) {
     GDN_CASE(16)

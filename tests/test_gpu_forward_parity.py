@@ -256,6 +256,30 @@ def test_262144_window_launch_equals_small_launches(gpu_device):
         assert torch.equal(xl2, xlin[s * 127:(s + 512) * 127]) and torch.equal(z2, z[s * 127:(s + 512) * 127]), s
 
 
+@pytest.mark.parametrize("d,bf16", [(64, False), (64, True), (128, False)])
+def test_large_launch_at_the_512_sensor_shape_runs_the_16_wave_kernel(d, bf16, gpu_device):
+    """BASELINE configs[4] (512 sensors, top-k 64, W=30) in a launch of more than 4 windows per CU: the row-gather
+    kernel then runs 16-wave workgroups (gdn_forward.hip, make_plan) — a different kernel instance from the 8-wave
+    one every small test exercises.  Same per-target arithmetic, so: bit for bit what 300-window launches of the
+    same rows give, the ragged tail included, and a few windows against the float64 oracle."""
+    n, w, k = 512, 30, 64
+    b = 4 * torch.cuda.get_device_properties(gpu_device).multi_processor_count + 37
+    model = random_params(n, w, k, d, seed=31)
+    p = {key: v.detach().clone() for key, v in model.state_dict().items()}
+    model = model.to(gpu_device).eval()
+    x = torch.rand((b, n, w), generator=torch.Generator().manual_seed(32))
+    xin = (x.bfloat16() if bf16 else x).to(gpu_device)
+    with torch.no_grad():
+        big = model(xin, None)
+        for s in (0, 300, b - 300):
+            assert torch.equal(model(xin[s:s + 300].contiguous(), None), big[s:s + 300]), s
+    pick = [0, 1, b // 2, b - 1]
+    p64 = {key: (v.double() if v.is_floating_point() else v) for key, v in p.items()}
+    ref = gdn_oracle.forward(p64, xin[pick].cpu().double(), k, graph=model.learned_graph.cpu(),
+                             storage="bf16" if bf16 else "fp32")
+    np.testing.assert_allclose(big[pick].cpu().double().numpy(), ref["out"].numpy(), atol=2e-4 if bf16 else 2e-6, rtol=0)
+
+
 @pytest.mark.parametrize("case", MODEL_CASES)
 def test_eval_forward_against_float64_oracle(case, gpu_device):
     """Accuracy rather than parity: the eval forward (fused, or staged + MLP for out_layer_num > 1) against
