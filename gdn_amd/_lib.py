@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDN_HIP_LIB", os.path.join(_HERE, "libgdn_hip.so"))   # override: diagnostic builds
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_int, _c_float, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
