@@ -559,6 +559,24 @@ __global__ __launch_bounds__(64 * NT) void gdn_bank_order_kernel(const uint16_t*
 #else
 #define GDN_FUSED_ATTR
 #endif
+// Wave priorities per phase (s_setprio): the two workgroups of a CU share every SIMD, and with equal priorities a
+// wave in its matrix-core phases (P: projection, M: aggregation product) waits for issue slots behind the other
+// workgroup's VALU-heavy phases (S: softmax, E: head).  Same-box A/B over 13 settings (tools/_diag/build_variant.sh,
+// tools/probe_fused_time.py), us per 32768 windows fp32 / bf16 storage: none 289.3 / 233.8; P3 S0 M3 E0 279.0 /
+// 216.9; every setting with M highest, P and E in between and S lowest 269-272 / 214-217 (P2 S0 M3 E1 kept):
+// -6.6 % / -8 %.  Same arithmetic, same bits.
+#ifndef GDN_K8_PRIO_T       // the staged gather-aggregate: tile staging, softmax, product, z stores
+#define GDN_K8_PRIO_T 2
+#define GDN_K8_PRIO_S 0
+#define GDN_K8_PRIO_M 3
+#define GDN_K8_PRIO_Z 1
+#endif
+#ifndef GDN_PRIO_P
+#define GDN_PRIO_P 2
+#define GDN_PRIO_S 0
+#define GDN_PRIO_M 3
+#define GDN_PRIO_E 1
+#endif
 template <int NT, int DC, int WK, int SL, int FMT>
 // two workgroups per CU (2 waves per SIMD, <= 256 registers) where the constants fit; the long-list /
 // long-window variants take the whole register file (accumulator registers as spill space) at one
@@ -657,6 +675,7 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
 
     // ------------------------------------------------------------ P
     {
+      __builtin_amdgcn_s_setprio(GDN_PRIO_P);
       f32x16 acc1[DC], accs;
 #pragma unroll
       for (int cb = 0; cb < DC; ++cb)
@@ -707,6 +726,7 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
             *reinterpret_cast<u32x4*>(smem + C::OFF_XF + ((((2 * wv + s) * DC + cb) * C::NPX + t) << 10) + lane * 16) = xf[t];
         }
     }
+    __builtin_amdgcn_s_setprio(GDN_PRIO_S);
     if (b == (int)blockIdx.x) { GDN_STAMP(5) }
     __syncthreads();                                           // B2: tile fragments + scalars visible
     if (b == (int)blockIdx.x) { GDN_STAMP(6) }
@@ -746,6 +766,7 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
       for (int cb = 0; cb < DC; ++cb) fx[buf][cb][0] = lds_frag(smem, xf_lane + ks * XF_KS + ((cb * C::NPX) << 10));
     };
     if (b == (int)blockIdx.x) { GDN_STAMP(7) }
+    __builtin_amdgcn_s_setprio(GDN_PRIO_M);      // see the note at the kernel's head
     scatter_terms<SL>(smem, k.scoff, ph);
     __builtin_amdgcn_sched_barrier(0);
     fetch_hi(0, 0);
@@ -773,6 +794,7 @@ __global__ __launch_bounds__(64 * NT, (DC == 2 && NT >= 3 && SL <= 16 && WK == 1
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    __builtin_amdgcn_s_setprio(GDN_PRIO_E);
     if (b == (int)blockIdx.x) { GDN_STAMP(8) }
     // ------------------------------------------------------------ E  (models/GDN.py:77-79,175-184)
     float part = 0.f;
@@ -937,6 +959,7 @@ __global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kern
 
   for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
     // ---- tile of window b -> LDS (16-bit terms), scalars -> LDS (log2 domain)
+    __builtin_amdgcn_s_setprio(GDN_K8_PRIO_T);     // phase priorities: see gdn_dense_fused_kernel
 #pragma unroll
     for (int u = 0; u < C::TU; ++u) {
       if (!tok[u]) continue;        // pad rows stay zero (the loads past row n read the next window)
@@ -958,6 +981,7 @@ __global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kern
     }
     __syncthreads();                                           // B1
     load_window(min(b + (int)gridDim.x, a.batch - 1));
+    __builtin_amdgcn_s_setprio(GDN_K8_PRIO_S);
 
     // ---- S
     unsigned ph[SL / 2], pl[SL / 2];
@@ -994,6 +1018,7 @@ __global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kern
           fx[buf][cb][t] = u32x4{u0.x, u0.y, u1.x, u1.y};
         }
     };
+    __builtin_amdgcn_s_setprio(GDN_K8_PRIO_M);
     scatter_terms<SL>(smem, scoff, ph);
     __builtin_amdgcn_sched_barrier(0);
     fetch(0, 0, C::NPX);
@@ -1021,6 +1046,7 @@ __global__ __launch_bounds__(64 * NT, SL <= 16 ? 2 : 1) void gdn_dense_attn_kern
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- z rows: register r = target 32wv + (r&3) + 8(r>>2) + 4h, lane = column
+    __builtin_amdgcn_s_setprio(GDN_K8_PRIO_Z);
     constexpr float UNSCALE = FMT == FMT_F16 ? 1.f / GDN_F16_ALPHA_SCALE : 1.f;
 #pragma unroll
     for (int cb = 0; cb < DC; ++cb)

@@ -34,5 +34,5 @@ for _ in range(reps):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     best, tot = min(best, us), tot + us
-knobs = {k: v for k, v in os.environ.items() if k.startswith("GDN_")}
+knobs = {k: os.path.basename(v) for k, v in os.environ.items() if k.startswith("GDN_")}
 print(f"B={B} {'bf16' if bf16 else 'fp32'} {knobs}: avg {tot / reps:.1f} us, best {best:.1f} us, checksum {float(out.sum()):.6f}")
