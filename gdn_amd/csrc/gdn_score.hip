@@ -247,12 +247,16 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, Se
   if (tid == 0) atomicExch(&st.arrive, 0u);
 }
 
+// 1024 threads x 32 keys: up to 32768 survivors stay in registers.  With 8 ranks a sensor has 262144 keys and a 16-bit
+// prefix bin keeps ~3 % of them per quantile: ~24 k survivors, which the 256-thread / 4096-key form re-read from
+// memory in each of its five passes (176 us of a 230 us select; 18 us now: tools/probe_select_sharded.py).
+constexpr int FIN_NT = 1024;
 // Finisher: digits first_pass..7 of every rank in ONE launch, one block per sensor, no global
 // hand-offs.  Reads the compacted buffer (FROM_B) — normally a handful of keys, <= 2048 stay in
 // registers (<= 4096), more (e.g. thousands of identical values) are re-read per digit — or, for inputs of a
 // single slice, the flat input itself.
 template <bool FROM_B>
-__global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, SelState* __restrict__ state,
+__global__ __launch_bounds__(FIN_NT) void select_finish_kernel(const KeyLayout kl, SelState* __restrict__ state,
                                                             int first_pass, const SelectArgs sa,
                                                             double* __restrict__ med_iqr) {
   __shared__ unsigned int hist[NQ][256];
@@ -269,13 +273,13 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, 
     prefix[tid] = st.prefix[tid];
     rem[tid] = st.rem[tid];
   }
-  constexpr int FK = 16;                      // keys per thread the finisher keeps in registers
-  const bool resident = cnt <= FK * 256;
+  constexpr int FK = 32;                      // keys per thread the finisher keeps in registers
+  const bool resident = cnt <= FK * FIN_NT;
   unsigned long long key[FK];
   if (resident) {
 #pragma unroll
     for (int u = 0; u < FK; ++u) {
-      const unsigned int i = tid + u * 256;
+      const unsigned int i = tid + u * FIN_NT;
       key[u] = i < cnt ? in[i] : FILLER;
     }
   }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, 
         if (prefix[q] == prefix[tid]) r = q;
       rep[tid] = r;
     }
-    for (int i = tid; i < NQ * 256; i += 256) (&hist[0][0])[i] = 0u;
+    for (int i = tid; i < NQ * 256; i += FIN_NT) (&hist[0][0])[i] = 0u;
     __syncthreads();
     unsigned long long pf[NQ];
     bool active[NQ];
@@ -297,22 +301,32 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const KeyLayout kl, 
       pf[q] = prefix[q];
       active[q] = rep[q] == q;
     }
-    auto tally = [&](unsigned long long k) {
+    // returns false when the key matches no rank's prefix any more (it never will again)
+    auto tally = [&](unsigned long long k) -> bool {
+      if (k == FILLER) return false;
       const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+      bool any = false;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (!active[q]) continue;
-        if (k != FILLER && (pass == 0 || ((k ^ pf[q]) >> (shift + 8)) == 0ull)) atomicAdd(&hist[q][digit], 1u);
+        if (pass == 0 || ((k ^ pf[q]) >> (shift + 8)) == 0ull) {
+          atomicAdd(&hist[q][digit], 1u);
+          any = true;
+        }
       }
+      return any;
     };
     if (resident) {
+      // a key that matched nothing is dropped from the register set: the later passes skip it with one compare
+      // (24 k survivors x 6 ranks x 5 passes of 64-bit shifts were 60 of the finisher's 67 us)
 #pragma unroll
-      for (int u = 0; u < FK; ++u) tally(key[u]);
+      for (int u = 0; u < FK; ++u)
+        if (!tally(key[u])) key[u] = FILLER;
     } else {
-      for (unsigned int i = tid; i < cnt; i += 256) tally(in[i]);
+      for (unsigned int i = tid; i < cnt; i += FIN_NT) tally(in[i]);
     }
     __syncthreads();
-    for (int q = wv; q < NQ; q += 4) locate_bin(hist[rep[q]], rem[q], pf[q], shift, lane, &prefix[q], &rem[q]);
+    for (int q = wv; q < NQ; q += FIN_NT / 64) locate_bin(hist[rep[q]], rem[q], pf[q], shift, lane, &prefix[q], &rem[q]);
     __syncthreads();
   }
   if (tid == 0) write_result(prefix, sa, s, med_iqr);
@@ -781,14 +795,14 @@ int run_select(const double* keys, int blocks, int n, int pitch, long long total
   }
   hipLaunchKernelGGL(select_init_kernel, dim3(n), dim3(256), 0, st, state, sa);
   if (slices == 1) {   // tiny input: everything in the finisher, straight from the input
-    hipLaunchKernelGGL(select_finish_kernel<false>, dim3(n), dim3(256), 0, st, kl, state, 0, sa, med_iqr);
+    hipLaunchKernelGGL(select_finish_kernel<false>, dim3(n), dim3(FIN_NT), 0, st, kl, state, 0, sa, med_iqr);
     return gdn_launch_status();
   }
   hipLaunchKernelGGL((select_pass_kernel<false, false>), dim3(slices, n), dim3(256), 0, st, kl, state, 0);
   hipLaunchKernelGGL((select_pass_kernel<false, false>), dim3(slices, n), dim3(256), 0, st, kl, state, 1);
   hipLaunchKernelGGL((select_pass_kernel<false, true>), dim3(slices, n), dim3(256), 0, st, kl, state, 2);
   // digits 3-7 on the survivors (normally a few percent of the keys) in one launch per sensor
-  hipLaunchKernelGGL(select_finish_kernel<true>, dim3(n), dim3(256), 0, st, kl, state, 3, sa, med_iqr);
+  hipLaunchKernelGGL(select_finish_kernel<true>, dim3(n), dim3(FIN_NT), 0, st, kl, state, 3, sa, med_iqr);
   return gdn_launch_status();
 }
 
