@@ -156,7 +156,8 @@ def test_captured_graph_is_dropped_when_a_parameter_changes(gpu_device):
     assert torch.allclose(ev.pred, before + 1.0, atol=1e-6)
 
 
-@pytest.mark.parametrize("t,n,ranks", [(5000, 23, 3), (32768 * 2, 16, 2), (2500, 7, 4)])
+@pytest.mark.parametrize("t,n,ranks", [(5000, 23, 3), (32768 * 2, 16, 2), (2500, 7, 4),
+                                        (32768 * 8, 127, 8)])      # the shape of an 8-rank bench step: ~24 k survivors per sensor
 def test_blocked_key_select_equals_whole_series_quantiles(t, n, ranks, gpu_device):
     """The owner-side half of the multi-GPU exchange on one GPU: keys built shard by shard (padded
     pitch, filler slots), laid out [rank, sensor, pitch] as all_to_all_single delivers them, selected
@@ -280,7 +281,7 @@ def test_threshold_sweep_full_size_against_oracle(gpu_device):
         np.testing.assert_allclose(got, score_oracle.best_performance(scores, labels, topk), rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("t", [32768, 20000, 5000, 40000])
+@pytest.mark.parametrize("t", [32768, 20000, 5000, 40000, 262144])
 def test_quantile_select_on_adversarial_error_distributions(t, gpu_device):
     """Every sensor's median / IQR must equal numpy's bit for bit whatever the shape of the error distribution:
     the one-workgroup select (t <= 32768) decides digit 0 by COUNTING around the top byte of tick 0's key and
