@@ -68,7 +68,8 @@ struct SelState {
   unsigned int hist[NQ][256];
   unsigned int arrive;
   unsigned int cnt_b;     // keys compacted into the workspace buffer
-  unsigned int pad0, pad1;
+  unsigned int digits_done;   // digits the prefixes hold: pass 0 also settles digit 1 when it can (see select_pass_kernel)
+  unsigned int pad1;
 };
 
 struct KeyLayout {
@@ -88,6 +89,7 @@ __global__ void select_init_kernel(SelState* __restrict__ state, const SelectArg
   if (threadIdx.x == 0) {
     st.arrive = 0u;
     st.cnt_b = 0u;
+    st.digits_done = 0u;
   }
 }
 
@@ -148,10 +150,18 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, Se
   const int s = blockIdx.y, g = blockIdx.x, G = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   SelState& st = state[s];
+  // Pass 0 usually settles TWO digits: the errors of a sensor almost always share the top byte of their keys (sign
+  // + 7 exponent bits), so next to the histogram of byte 0 it histograms byte 1 of the keys whose byte 0 equals that
+  // of the sensor's first key; if every quantile's rank falls into that byte-0 bin the last workgroup locates
+  // digit 1 as well and the pass-1 launch returns at once (it is still launched: the sequence is captured in
+  // graphs).  One streaming pass over the keys less: 14.5 -> ~5 us of an 86 us select at the 8-rank shape.
+  if (!FROM_B && !COMPACT && pass == 1 && st.digits_done >= 2u) return;
   const unsigned int slots = (unsigned int)kl.blocks * (unsigned int)kl.pitch;
   const unsigned int cnt = FROM_B ? st.cnt_b : slots;
   unsigned long long* outb = kl.bufb + (size_t)s * slots;
   const int shift = 56 - 8 * pass;
+  const bool two = !FROM_B && !COMPACT && pass == 0;                    // uniform
+  const unsigned int dref = two ? (unsigned int)(kl.keys[(size_t)s * kl.pitch] >> 56) : 0u;   // block 0, slot 0
   unsigned long long pf[NQ];
   bool active[NQ];
 #pragma unroll
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, Se
       if constexpr (COMPACT) {
         if (any) stage[atomicAdd(&n_stage, 1u)] = key[u];
       }
+      if (two && real && digit == dref) atomicAdd(&hist[1][(unsigned int)(key[u] >> 48) & 255u], 1u);
     }
     if constexpr (COMPACT) {
       __syncthreads();
@@ -236,6 +247,23 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, Se
   __syncthreads();
   for (int q = wv; q < NQ; q += 4) locate_bin(hist[st.rep[q]], st.rem[q], pf[q], shift, lane, &npf[q], &nrem[q]);
   __syncthreads();
+  unsigned int done = (unsigned int)pass + 1u;
+  if (two) {
+    bool inside = dref != 255u;                                  // (255: the filler's byte)
+    for (int q = 0; q < NQ; ++q) inside = inside && (unsigned int)(npf[q] >> 56) == dref;
+    if (inside) {                                                // uniform: digit 1 from the conditional histogram
+      __shared__ unsigned long long npf2[NQ];
+      __shared__ int nrem2[NQ];
+      for (int q = wv; q < NQ; q += 4) locate_bin(hist[1], nrem[q], npf[q], shift - 8, lane, &npf2[q], &nrem2[q]);
+      __syncthreads();
+      if (tid < NQ) {
+        npf[tid] = npf2[tid];
+        nrem[tid] = nrem2[tid];
+      }
+      __syncthreads();
+      done = 2u;
+    }
+  }
   if (tid < NQ) {
     st.prefix[tid] = npf[tid];
     st.rem[tid] = nrem[tid];
@@ -244,7 +272,10 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const KeyLayout kl, Se
       if (npf[q] == npf[tid]) r = q;
     st.rep[tid] = r;
   }
-  if (tid == 0) atomicExch(&st.arrive, 0u);
+  if (tid == 0) {
+    st.digits_done = done;
+    atomicExch(&st.arrive, 0u);
+  }
 }
 
 // 1024 threads x 32 keys: up to 32768 survivors stay in registers.  With 8 ranks a sensor has 262144 keys and a 16-bit
